@@ -1,0 +1,281 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-ends for the two CPU checkers.
+
+* ``load_port()``  -> oracle/libpxf_oracle[_omp].so, our plain-C restatement (pxf_oracle.c).
+* ``load_ref()``   -> oracle/_ref/libpxfref_*.so, the reference's own Fortran compiled in place
+                      by oracle/Makefile (Fortran ABI: every argument by reference, symbol
+                      ``name_``, ``num`` an int32).
+
+Both return an object with four namespaces that mimic the f2py modules the reference's Python
+imports (``surfacesf``, ``woltsurf``, ``zernsurf``, ``transformationsf``; compiletrace.sh:1-6), with
+the f2py call signatures: SoA float64 columns mutated in place, ``num``
+implied by ``len(x)``.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def build(quiet=True):
+    """Run oracle/Makefile (C restatement always; _ref only where /root/reference exists)."""
+    subprocess.run(["make", "-C", HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def _f64(a):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.ndim == 1):
+        raise TypeError("ray columns must be 1-D C-contiguous float64 arrays (f2py intent(inout))")
+    return a.ctypes.data_as(_dp)
+
+
+def _cols(*arrs):
+    n = len(arrs[0])
+    for a in arrs:
+        if len(a) != n:
+            raise ValueError("ray columns differ in length")
+    return [_f64(a) for a in arrs], n
+
+
+def _i32(a):
+    a = np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def _f64in(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(_dp)
+
+
+# --------------------------------------------------------------------------------------------
+def load_port(omp=False):
+    path = os.path.join(HERE, "libpxf_oracle_omp.so" if omp else "libpxf_oracle.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    d, i64, i32 = C.c_double, C.c_int64, C.c_int32
+
+    def sig(name, *argtypes, restype=None):
+        f = getattr(lib, name)
+        f.argtypes = list(argtypes)
+        f.restype = restype
+        return f
+
+    P = _dp
+    f_flat = sig("orc_flat", *[P] * 9, i64)
+    f_flatopd = sig("orc_flatopd", *[P] * 10, i64, d)
+    f_conic = sig("orc_conic", *[P] * 9, i64, d, d)
+    f_conicopd = sig("orc_conicopd", *[P] * 10, i64, d, d, d)
+    f_wp = sig("orc_wolterprimary", *[P] * 9, i64, d, d, d)
+    f_wpo = sig("orc_wolterprimaryopd", *[P] * 10, i64, d, d, d, d)
+    f_ws = sig("orc_woltersecondary", *[P] * 9, i64, d, d, d)
+    f_tz = sig("orc_tracezern", *[P] * 9, i64, P, _ip, _ip, i32, d, restype=C.c_int)
+    f_tzo = sig("orc_tracezernopd", *[P] * 10, i64, P, _ip, _ip, i32, d, d, restype=C.c_int)
+    f_zs = sig("orc_zernset", d, d, _ip, _ip, i32, P, P, P)
+    f_tr = sig("orc_transform", *[P] * 9, i64, *[d] * 6)
+    f_itr = sig("orc_itransform", *[P] * 9, i64, *[d] * 6)
+    f_refl = sig("orc_reflect", *[P] * 6, i64)
+    f_rg = sig("orc_radgrat", *[P] * 5, d, i64, d, d)
+    f_rgw = sig("orc_radgratw", *[P] * 6, i64, d, d)
+    f_par = sig("orc_wolter_params", d, d, d, P, P, P)
+
+    def flat(x, y, z, l, m, n, ux, uy, uz):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_flat(*p, num)
+
+    def flatopd(x, y, z, l, m, n, ux, uy, uz, opd, nr):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz, opd)
+        f_flatopd(*p, num, nr)
+
+    def conic(x, y, z, l, m, n, ux, uy, uz, R, K):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_conic(*p, num, R, K)
+
+    def conicopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        f_conicopd(*p, num, R, K, nr)
+
+    def wolterprimary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_wp(*p, num, r0, z0, psi)
+
+    def wolterprimaryopd(opd, x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        f_wpo(*p, num, r0, z0, psi, nr)
+
+    def woltersecondary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_ws(*p, num, r0, z0, psi)
+
+    def tracezern(x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        ck, cp = _f64in(coeff)
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        if f_tz(*p, num, cp, rp, ap, len(ck), rad) != 0:
+            raise ValueError("tracezern: (rorder, aorder) outside the reference's radial table")
+
+    def tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        ck, cp = _f64in(coeff)
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        if f_tzo(*p, num, cp, rp, ap, len(ck), rad, nr) != 0:
+            raise ValueError("tracezernopd: (rorder, aorder) outside the reference's radial table")
+
+    def zernset(rho, theta, rorder, aorder):
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        out = [np.zeros(len(rk)) for _ in range(3)]
+        f_zs(rho, theta, rp, ap, len(rk), *[_f64(o) for o in out])
+        return out
+
+    def transform(x, y, z, l, m, n, ux, uy, uz, tx, ty, tz, rx, ry, rz):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_tr(*p, num, tx, ty, tz, rx, ry, rz)
+
+    def itransform(x, y, z, l, m, n, ux, uy, uz, tx, ty, tz, rx, ry, rz):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_itr(*p, num, tx, ty, tz, rx, ry, rz)
+
+    def reflect(l, m, n, ux, uy, uz):
+        p, num = _cols(l, m, n, ux, uy, uz)
+        f_refl(*p, num)
+
+    def radgrat(x, y, l, m, n, wave, dpermm, order):
+        p, num = _cols(x, y, l, m, n)
+        f_rg(*p, float(wave), num, dpermm, order)
+
+    def radgratw(x, y, l, m, n, wave, dpermm, order):
+        p, num = _cols(x, y, l, m, n, wave)
+        f_rgw(*p, num, dpermm, order)
+
+    def wolter_params(r0, z0, psi=1.):
+        o = [C.c_double() for _ in range(3)]
+        f_par(r0, z0, psi, *[C.byref(v) for v in o])
+        return tuple(v.value for v in o)
+
+    return SimpleNamespace(
+        kind="port", omp=omp,
+        surfacesf=SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd),
+        woltsurf=SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
+                                 woltersecondary=woltersecondary),
+        zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
+        transformationsf=SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
+                                         radgrat=radgrat, radgratw=radgratw),
+        wolter_params=wolter_params)
+
+
+# --------------------------------------------------------------------------------------------
+def ref_available(omp=False):
+    sfx = "_omp" if omp else ""
+    return all(os.path.exists(os.path.join(HERE, "_ref", "libpxfref_%s%s.so" % (m, sfx)))
+               for m in ("surfacesf", "woltsurf", "zernsurf", "transformationsf"))
+
+
+def load_ref(omp=False):
+    """The real reference (Fortran ABI).  Raises FileNotFoundError when oracle/_ref is absent."""
+    if not ref_available(omp):
+        raise FileNotFoundError("oracle/_ref not built (needs /root/reference + flang: make -C oracle ref)")
+    sfx = "_omp" if omp else ""
+    L = {m: C.CDLL(os.path.join(HERE, "_ref", "libpxfref_%s%s.so" % (m, sfx)))
+         for m in ("surfacesf", "woltsurf", "zernsurf", "transformationsf")}
+
+    def fn(mod, name):
+        f = getattr(L[mod], name + "_")
+        f.restype = None
+        return f
+
+    def num32(num):
+        if num > 2 ** 31 - 1:
+            raise OverflowError("reference `num` is a default INTEGER (int32)")
+        return C.byref(C.c_int32(num))
+
+    def dref(v):
+        return C.byref(C.c_double(float(v)))
+
+    def mk9(mod, name, nscal):
+        f = fn(mod, name)
+
+        def call(x, y, z, l, m, n, ux, uy, uz, *scal):
+            assert len(scal) == nscal
+            p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+            f(*p, num32(num), *[dref(s) for s in scal])
+        return call
+
+    def mk10(mod, name, nscal):
+        f = fn(mod, name)
+
+        def call(opd, x, y, z, l, m, n, ux, uy, uz, *scal):
+            assert len(scal) == nscal
+            p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+            f(*p, num32(num), *[dref(s) for s in scal])
+        return call
+
+    f_flatopd = fn("surfacesf", "flatopd")
+
+    def flatopd(x, y, z, l, m, n, ux, uy, uz, opd, nr):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz, opd)
+        f_flatopd(*p, num32(num), dref(nr))
+
+    f_tz = fn("zernsurf", "tracezern")
+    f_tzo = fn("zernsurf", "tracezernopd")
+    f_zs = fn("zernsurf", "zernset")
+
+    def tracezern(x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        ck, cp = _f64in(coeff)
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        f_tz(*p, num32(num), cp, rp, ap, C.byref(C.c_int32(len(ck))), dref(rad))
+
+    def tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        ck, cp = _f64in(coeff)
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        f_tzo(*p, num32(num), cp, rp, ap, C.byref(C.c_int32(len(ck))), dref(rad), dref(nr))
+
+    def zernset(rho, theta, rorder, aorder):
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        out = [np.zeros(len(rk)) for _ in range(3)]
+        f_zs(dref(rho), dref(theta), rp, ap, C.byref(C.c_int32(len(rk))), *[_f64(o) for o in out])
+        return out
+
+    f_refl = fn("transformationsf", "reflect")
+
+    def reflect(l, m, n, ux, uy, uz):
+        p, num = _cols(l, m, n, ux, uy, uz)
+        f_refl(*p, num32(num))
+
+    f_rg = fn("transformationsf", "radgrat")
+    f_rgw = fn("transformationsf", "radgratw")
+
+    def radgrat(x, y, l, m, n, wave, dpermm, order):
+        p, num = _cols(x, y, l, m, n)
+        f_rg(*p, dref(wave), num32(num), dref(dpermm), dref(order))
+
+    def radgratw(x, y, l, m, n, wave, dpermm, order):
+        p, num = _cols(x, y, l, m, n, wave)
+        f_rgw(*p, num32(num), dref(dpermm), dref(order))
+
+    return SimpleNamespace(
+        kind="reference", omp=omp,
+        surfacesf=SimpleNamespace(flat=mk9("surfacesf", "flat", 0), flatopd=flatopd,
+                                  conic=mk9("surfacesf", "conic", 2),
+                                  conicopd=mk10("surfacesf", "conicopd", 3)),
+        woltsurf=SimpleNamespace(wolterprimary=mk9("woltsurf", "wolterprimary", 3),
+                                 wolterprimaryopd=mk10("woltsurf", "wolterprimaryopd", 4),
+                                 woltersecondary=mk9("woltsurf", "woltersecondary", 3)),
+        zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
+        transformationsf=SimpleNamespace(transform=mk9("transformationsf", "transform", 6),
+                                         itransform=mk9("transformationsf", "itransform", 6),
+                                         reflect=reflect, radgrat=radgrat, radgratw=radgratw))

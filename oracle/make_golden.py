@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- regenerate tests/golden/*.npz from the REAL reference.
+
+Runs only in the build container (needs /root/reference and oracle/_ref, i.e. the reference's
+own Fortran compiled in place by oracle/Makefile).  What it records is DATA ONLY: seeded inputs
+and the outputs the reference produced for them.  No reference source text is stored.
+
+  native_cases.npz   every case of oracle/cases.py through the flang-compiled Fortran entry
+                     points (surfacesf / woltsurf / zernsurf / transformationsf).
+  chain_config2.npz  SURVEY 8d config-2 two-bounce chain, N=4096, + focal rmsCentroid.
+  config1.npz        BASELINE config 1: np.random.seed(0); sources.pointsource(0.01, 1e5)
+                     (the reference's own sources.py) -> transform -> flat -> reflect;
+                     per-column SHA-256 of the outputs + the first 64 rays.
+  wrappers.npz       the reference's own transformations.py imported over a `PyXFocus`
+                     package shim whose `transformationsf` is the compiled Fortran: coords
+                     bookkeeping, applyT/applyTPos, `ind` handling, vignette, radgrat dispatch.
+  sources.npz        the reference's own sources.py under fixed np.random seeds.
+
+analyses.py / surfaces.py are NOT importable here (they import the un-vendored `utilities`
+package and astropy); their three-line wrappers/reductions are restated from the text and are
+pinned only through the native entry points they call -- stated in DESIGN.md.
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import api, cases  # noqa: E402
+
+REF = os.environ.get("PXF_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+NGOLD = 256
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def shim_reference_python(ref):
+    """Make `import PyXFocus.transformationsf / transformMod` resolve: the former to the compiled
+    Fortran (f2py-style adapters of oracle/api.py), the latter to the reference's own file."""
+    pkg = types.ModuleType("PyXFocus")
+    pkg.__path__ = []
+    sys.modules["PyXFocus"] = pkg
+    tf = types.ModuleType("PyXFocus.transformationsf")
+    for k, v in vars(ref.transformationsf).items():
+        setattr(tf, k, v)
+    sys.modules["PyXFocus.transformationsf"] = tf
+    pkg.transformationsf = tf
+    pkg.transformMod = _load_by_path("PyXFocus.transformMod", os.path.join(REF, "transformMod.py"))
+    tran = _load_by_path("PyXFocus.transformations", os.path.join(REF, "transformations.py"))
+    src = _load_by_path("PyXFocus.sources", os.path.join(REF, "sources.py"))
+    return tran, src
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = api.load_ref()
+    tran, src = shim_reference_python(ref)
+
+    # ---- native cases ------------------------------------------------------------------
+    blob = {}
+    names = []
+    for name, fn, cols, args in cases.cases(num=NGOLD, seed=1234):
+        names.append(name + "|" + fn)
+        for k, v in cols.items():
+            blob["%s/in/%s" % (name, k)] = v.copy()
+        for i, a in enumerate(args):
+            blob["%s/arg/%d" % (name, i)] = np.asarray(a)
+        cases.call(ref, fn, cols, args)
+        for k in cases.SIG[fn].split():
+            blob["%s/out/%s" % (name, k)] = cols[k]
+    blob["__names__"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "native_cases.npz"), **blob)
+    print("native_cases:", len(names), "cases")
+
+    # ---- config-2 chain ----------------------------------------------------------------
+    rng = np.random.default_rng(2)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    c = cases.annulus_rays(rng, 4096, rin, rout, 0.)
+    cin = {k: v.copy() for k, v in c.items()}
+    cases.chain_config2(ref, c)
+    blob = {"in/" + k: v for k, v in cin.items()}
+    blob.update({"out/" + k: v for k, v in c.items()})
+    blob["rms_centroid"] = np.array(cases.rms_centroid(c["x"], c["y"]))
+    np.savez_compressed(os.path.join(OUT, "chain_config2.npz"), **blob)
+    print("chain_config2: rmsCentroid = %.6e mm" % blob["rms_centroid"])
+
+    # ---- config 1 (plumbing) -----------------------------------------------------------
+    np.random.seed(0)
+    rays = src.pointsource(0.01, 100000)
+    ins = [r.copy() for r in rays]
+    tran.transform(rays, 0, 0, -100, 0, 0, 0)
+    a = rays[1:]
+    ref.surfacesf.flat(*a)                    # surfaces.flat(rays) -> surfacesf.flat (surfaces.py:27-28)
+    tran.reflect(rays)
+    blob = {"seed": np.array(0), "ang": np.array(0.01), "num": np.array(100000)}
+    for k, vin, vout in zip(cases.ALLCOLS, ins, rays):
+        blob["sha_in/" + k] = np.array(sha(vin))
+        blob["sha_out/" + k] = np.array(sha(vout))
+        blob["head_in/" + k] = vin[:64].copy()
+        blob["head_out/" + k] = vout[:64].copy()
+    np.savez_compressed(os.path.join(OUT, "config1.npz"), **blob)
+    print("config1: sha(x_out) =", blob["sha_out/x"])
+
+    # ---- reference Python wrappers over the compiled Fortran ------------------------------
+    rng = np.random.default_rng(77)
+    blob = {}
+
+    def put(prefix, rays):
+        for k, v in zip(cases.ALLCOLS, rays):
+            blob["%s/%s" % (prefix, k)] = np.array(v, copy=True)
+
+    def fresh(n=300):
+        c = cases._randrays(rng, n)
+        return [c[k] for k in cases.ALLCOLS]
+
+    # coords bookkeeping through a sequence of transforms + applyT both ways
+    rays = fresh()
+    put("coords/in", rays)
+    orig = tran.copy_rays(rays)
+    coords = tran.newCoords()
+    seq = [(1., -2., 3., 0.1, 0.2, -0.3), (0., 0., 50., 0., 0., 1.2), (-4., 0.5, 0., -0.7, 0., 0.)]
+    for t in seq:
+        tran.transform(rays, *t, coords=coords)
+    tran.itransform(rays, 0.3, 0.2, 0.1, 0.01, -0.02, 0.03, coords=coords)
+    blob["coords/seq"] = np.array(seq)
+    blob["coords/iseq"] = np.array([0.3, 0.2, 0.1, 0.01, -0.02, 0.03])
+    put("coords/out", rays)
+    blob["coords/matrices"] = np.array(coords)
+    put("coords/applyT_fwd", tran.applyT(orig, coords))
+    put("coords/applyT_inv", tran.applyT(rays, coords, inverse=True))
+    blob["coords/applyTPos_fwd"] = np.array(tran.applyTPos(orig[1], orig[2], orig[3], coords))
+    blob["coords/applyTPos_inv"] = np.array(tran.applyTPos(rays[1], rays[2], rays[3], coords, inverse=True))
+    blob["coords/rotationM"] = tran.rotationM(0.3, -0.4, 0.5)
+    blob["coords/rotationM_inv"] = tran.rotationM(0.3, -0.4, 0.5, inverse=True)
+    blob["coords/translationM"] = tran.translationM(1., 2., 3.)
+
+    # `ind` handling: bool mask, index array, np.where tuple
+    for tag, mk in {"mask": lambda n: rng.random(n) < 0.4,
+                    "index": lambda n: rng.permutation(n)[: n // 3],
+                    "where": lambda n: np.where(rng.random(n) < 0.5)}.items():
+        rays = fresh()
+        ind = mk(len(rays[0]))
+        put("ind_%s/in" % tag, rays)
+        blob["ind_%s/ind" % tag] = np.asarray(ind[0] if isinstance(ind, tuple) else ind)
+        tran.transform(rays, 1., 2., 3., 0.1, 0.2, 0.3, ind=ind)
+        tran.reflect(rays, ind=ind)
+        tran.itransform(rays, -1., 0., 2., 0., 0.5, 0., ind=ind)
+        put("ind_%s/out" % tag, rays)
+
+    # vignette: default (|d|^2 > .1), mask, index
+    rays = fresh()
+    kill = rng.random(len(rays[0])) < 0.3
+    for k in (4, 5, 6):
+        rays[k][kill] = 0.
+    rays[6][5] = np.nan
+    put("vignette/in", rays)
+    put("vignette/default", tran.vignette(rays))
+    msk = rng.random(len(rays[0])) < 0.5
+    blob["vignette/mask"] = msk
+    put("vignette/bymask", tran.vignette(rays, ind=msk))
+    idx = rng.permutation(len(rays[0]))[:57]
+    blob["vignette/index"] = idx
+    put("vignette/byindex", tran.vignette(rays, ind=idx))
+
+    # radgrat dispatch: scalar wave -> radgrat, ndarray -> radgratw; with and without ind
+    hub = 11832.
+    for tag in ("scalar", "array", "scalar_ind", "array_ind"):
+        c = cases._randrays(rng, 300)
+        c["x"] = rng.uniform(-50, 50, 300)
+        c["y"] = hub + rng.uniform(-50, 50, 300)
+        c["l"] = rng.normal(0, 1e-3, 300)
+        c["m"] = np.full(300, -0.99965)
+        c["n"] = np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2) * rng.choice([-1., 1.], 300)
+        rays = [c[k] for k in cases.ALLCOLS]
+        put("radgrat_%s/in" % tag, rays)
+        wave = rng.uniform(1., 3., 300) if tag.startswith("array") else 2.4
+        ind = (rng.random(300) < 0.5) if tag.endswith("ind") else None
+        blob["radgrat_%s/wave" % tag] = np.asarray(wave)
+        if ind is not None:
+            blob["radgrat_%s/ind" % tag] = ind
+        tran.radgrat(rays, 160. / hub, 1., wave, ind=ind)
+        put("radgrat_%s/out" % tag, rays)
+
+    # pointTo
+    rays = fresh()
+    put("pointto/in", rays)
+    tran.pointTo(rays, 1., -2., 5000., reverse=1.)
+    put("pointto/out", rays)
+    np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **blob)
+    print("wrappers:", len(blob), "arrays")
+
+    # ---- sources -----------------------------------------------------------------------
+    blob = {}
+    for tag, seed, fn, args in [("pointsource", 11, src.pointsource, (0.01, 64)),
+                                ("circularbeam", 12, src.circularbeam, (50., 64)),
+                                ("annulus", 13, src.annulus, (220., 220.65, 64)),
+                                ("annulus_zhat", 14, src.annulus, (100., 150., 64, 1.)),
+                                ("subannulus", 15, src.subannulus, (220., 221., 0.5, 64)),
+                                ("subannulus_zhat", 16, src.subannulus, (220., 221., 0.5, 64, -1.)),
+                                ("xslit", 17, src.xslit, (-5., 5., 64)),
+                                ("rectArray", 18, src.rectArray, (10., 20., 8)),
+                                ("rectbeam", 19, src.rectbeam, (3., 4., 64)),
+                                ("convergingbeam", 20, src.convergingbeam, (8400., 220., 221., -0.2, 0.3, 64, 1.5)),
+                                ("convergingbeam2", 21, src.convergingbeam2, (8400., 200., 220., -10., 10., 64, 1.5)),
+                                ("gaussianBeam", 22, src.gaussianBeam, (0.01, 64)),
+                                ("fanBeam", 23, src.fanBeam, (0.01, 0.02, 8)),
+                                ("circFan", 24, src.circFan, (0.02, 4, 6))]:
+        np.random.seed(seed)
+        rays = fn(*args)
+        blob[tag + "/seed"] = np.array(seed)
+        blob[tag + "/args"] = np.array(args, dtype=float)
+        for k, v in zip(cases.ALLCOLS, rays):
+            blob["%s/%s" % (tag, k)] = np.asarray(v, dtype=float)
+    np.savez_compressed(os.path.join(OUT, "sources.npz"), **blob)
+    print("sources:", len(blob), "arrays")
+
+
+if __name__ == "__main__":
+    main()
