@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/sec through the two-bounce Wolter-I trace (BASELINE.json metric) on MI355X.
+
+Workload (BASELINE config 2 / SURVEY 8d): per GPU 1e8 rays, annulus [primrad(z0), primrad(z0+L)],
+r0=220, z0=8400, psi=1, L=100, fp64; one STEP = the reference call chain, one HIP launch per
+PyXFocus API call (the drop-in contract):
+
+    tran.transform(rays,0,0,-(z0+2L),0,0,0) -> surf.wolterprimary -> tran.reflect
+        -> surf.woltersecondary -> tran.reflect -> surf.flat            (576 algorithmic B/ray)
+
+Every step traces a FRESH bundle (the chain mutates rays in place, so re-tracing a traced bundle
+would be different work): K+W bundles are generated on the device before the timed region
+(8 GB each at 1e8 rays; 288 GB of HBM3E holds the default 12 with room to spare).  Inputs are
+therefore resident in HBM when timing starts; nothing is generated, copied or reduced inside it.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): rays shard by global index, each rank
+traces its own 1e8 rays (weak scaling), no collective in the data path.  After the timed region
+the ranks all-reduce the focal-plane moments and all-gather the focal (x,y) over RCCL/xGMI -- the
+one exchange the path has -- and report its time separately.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+R0, Z0, PSI, LMIR = 220., 8400., 1., 100.
+BYTES = {"transform": 144, "wolterprimary": 96, "reflect": 72, "woltersecondary": 96, "flat": 96}
+CHAIN = ["transform", "wolterprimary", "reflect", "woltersecondary", "reflect", "flat"]
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def chain_step(rays, tran, surf, ev=None):
+    """One pass of the hot path.  `ev`: optional list of 7 torch.cuda.Event to bracket each launch."""
+    def mark(i):
+        if ev is not None:
+            ev[i].record()
+    mark(0)
+    tran.transform(rays, 0, 0, -(Z0 + 2 * LMIR), 0, 0, 0)
+    mark(1)
+    surf.wolterprimary(rays, R0, Z0, PSI)
+    mark(2)
+    tran.reflect(rays)
+    mark(3)
+    surf.woltersecondary(rays, R0, Z0, PSI)
+    mark(4)
+    tran.reflect(rays)
+    mark(5)
+    surf.flat(rays)
+    mark(6)
+
+
+def cpu_baseline(target_seconds=12.0):
+    """Reference Fortran (oracle/_ref, OpenMP build) -- or our C port if _ref did not travel --
+    timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import api, cases
+    kind, be = "port", None
+    try:
+        if api.ref_available(omp=True):
+            be, kind = api.load_ref(omp=True), "reference"
+    except OSError:
+        be = None
+    if be is None:
+        be = api.load_port(omp=True)
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    n = 4_000_000
+    rng = np.random.default_rng(0)
+    rin, rout = cases.primrad(Z0), cases.primrad(Z0 + LMIR)
+    src = cases.annulus_rays(rng, n, rin, rout, 0.)
+    c = {k: v.copy() for k, v in src.items()}
+    cases.chain_config2(be, c)                      # warm-up (page faults, thread pool)
+    reps, spent = 0, 0.0
+    while spent < target_seconds and reps < 200:
+        c = {k: v.copy() for k, v in src.items()}
+        t0 = time.perf_counter()
+        cases.chain_config2(be, c)
+        spent += time.perf_counter() - t0
+        reps += 1
+    return {"value": n * reps / spent, "unit": "rays/s", "cores": cores, "kind": kind,
+            "sample": "%d x %d rays, same config-2 chain, %s, %.1f s of CPU time" % (
+                reps, n, "PyXFocus Fortran compiled with flang -O2 -fopenmp (oracle/_ref)" if kind == "reference"
+                else "C restatement oracle/pxf_oracle.c -O2 -fopenmp", spent)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rays", type=float, default=1e8, help="rays per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--pool-gb", type=float, default=200.0, help="HBM budget for pre-generated bundles")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+    n_gpus = world
+
+    import pyxfocus_amd.analyses as anal
+    import pyxfocus_amd.sources as sources
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from pyxfocus_amd import conicsolve as con
+
+    N = int(args.rays)
+    K, W = args.steps, args.warmup
+    rin, rout = float(con.primrad(Z0, R0, Z0)), float(con.primrad(Z0 + LMIR, R0, Z0))
+    bundle_gb = 80.0 * N / 1e9
+    pool = max(1, min(K, int(args.pool_gb // max(bundle_gb, 1e-9))))
+
+    def fresh(i):
+        # global ray index: rank r owns [r*N, (r+1)*N) of step i's bundle -> independent of n_gpus
+        return sources.annulus(rin, rout, N, rng="philox", seed=1000 + i, first_index=rank * N)
+
+    # ---- parity spot check on this rank's first rays (outside the timed region) ------------
+    parity = None
+    if rank == 0:
+        from oracle import api, cases
+        port = api.load_port()
+        chk = min(N, 100_000)
+        r0_ = sources.annulus(rin, rout, chk, rng="philox", seed=999)
+        host = {k: v.cpu().numpy() for k, v in zip(cases.ALLCOLS, r0_)}
+        cases.chain_config2(port, host)
+        chain_step(r0_, tran, surf)
+        got = {k: v.cpu().numpy() for k, v in zip(cases.ALLCOLS, r0_)}
+        err = np.sqrt(np.mean(sum((got[k] - host[k]) ** 2 for k in "xyz")))
+        bit = all(np.array_equal(got[k], host[k]) for k in cases.ALLCOLS)
+        parity = {"rays": chk, "rms_pos_err_mm_vs_oracle": float(err), "bit_identical": bool(bit)}
+        del r0_
+
+    # ---- warm-up -------------------------------------------------------------------------
+    for i in range(W):
+        b = fresh(-1 - i)
+        chain_step(b, tran, surf)
+        del b
+    torch.cuda.synchronize()
+
+    # ---- timed region: EXACTLY K steps -----------------------------------------------------
+    bundles = [fresh(i) for i in range(pool)]
+    regen = max(0, K - pool)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(K)]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        if i >= pool:                       # only if K exceeds what HBM can hold pre-generated
+            bundles[i % pool] = fresh(i)
+        chain_step(bundles[i % pool], tran, surf, ev[i])
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations from the HIP events recorded inside the timed region -----------
+    per = {}
+    for i in range(K):
+        for j, name in enumerate(CHAIN):
+            per.setdefault((j, name), []).append(ev[i][j].elapsed_time(ev[i][j + 1]))
+    kern = []
+    for (j, name), ms in sorted(per.items()):
+        avg = float(np.mean(ms))
+        kern.append({"launch": j, "kernel": name, "avg_ms": avg, "bytes_per_ray": BYTES[name],
+                     "GBps": BYTES[name] * N / (avg * 1e-3) / 1e9})
+    dom = max(kern, key=lambda k: k["avg_ms"])
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            ent = tj.get(dom["kernel"])
+            if ent and int(ent.get("rays", 0)) == N:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom["bytes_per_ray"] * N, "avg_launch_ms": dom["avg_ms"]}
+    chain_gbps = 576.0 * N * K / (sum(k["avg_ms"] for k in kern) * K * 1e-3) / 1e9
+
+    # ---- focal plane: global metric via all-reduce, and the all-gather the north-star names ----
+    last = bundles[(K - 1) % pool]
+    rms = anal.rmsCentroid(last, group=True if dist else None)
+    gather = None
+    if dist and not args.no_gather:
+        try:
+            from pyxfocus_amd import dist as pdist
+            torch.cuda.synchronize(); dist.barrier()
+            g0 = time.perf_counter()
+            gx, gy = pdist.all_gather_focal([last[1], last[2]])
+            torch.cuda.synchronize(); dist.barrier()
+            gather = {"ms": (time.perf_counter() - g0) * 1e3, "rays": int(gx.shape[0]),
+                      "GB_received_per_rank": 16.0 * gx.shape[0] * (world - 1) / world / 1e9}
+            del gx, gy
+        except Exception as e:  # the trace result must survive a collective problem
+            gather = {"error": repr(e)[:200]}
+
+    out = None
+    if rank == 0:
+        value = N * n_gpus * K / elapsed
+        out = {"metric": "rays/sec through two-bounce Wolter-I trace", "value": value, "unit": "rays/s",
+               "n_gpus": n_gpus, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
+               "config": {"workload": "config2: %g rays/GPU annulus -> transform -> wolterprimary -> reflect -> "
+                                      "woltersecondary -> reflect -> flat; r0=220 z0=8400 psi=1 L=100; one HIP "
+                                      "launch per PyXFocus call" % N,
+                          "rays_per_gpu": N, "launches_per_step": 6, "algorithmic_bytes_per_ray": 576,
+                          "parallelism": "ray-sharded x%d, no data-path collective" % n_gpus,
+                          "bundles_pregenerated": pool, "bundles_regenerated_in_timed_region": regen},
+               "roofline": roofline,
+               "chain_GBps": chain_gbps, "chain_frac_of_hbm_peak": chain_gbps / HBM_PEAK_GBS,
+               "kernels": kern, "focal_rms_centroid_mm": rms, "parity": parity, "focal_gather": gather}
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)[:200]}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+/*
+ * pxf.h -- C ABI of libpxf_hip.so, the MI355X (gfx950) ray-trace core that drops in behind
+ * PyXFocus' f2py extension modules (compiletrace.sh:1-6 in the reference tree).
+ *
+ * One entry point per reference Fortran subroutine on the hot path.  Argument ORDER and
+ * MEANING follow the Fortran subroutine each one replaces (cited per function, file:line in
+ * the reference); the differences are the ones a C ABI needs:
+ *     - `num` is int64_t by value (the reference's default INTEGER caps a call at 2^31-1 rays),
+ *     - scalars are passed by value,
+ *     - every ray column is a DEVICE pointer to `num` contiguous float64 (structure-of-arrays:
+ *       the PyXFocus ray bundle is the list [opd,x,y,z,l,m,n,ux,uy,uz], sources.py:1-15),
+ *     - two trailing arguments: `mask` (NULL, or a device uint8[num]; rays with mask[i]==0 are
+ *       left untouched -- this is the reference wrappers' `ind=` gather/compute/scatter,
+ *       surfaces.py:17-24 / transformations.py:20-27, done as an in-kernel predicate) and
+ *       `stream` (a hipStream_t passed as void*; NULL = the default stream).
+ *
+ * All calls are asynchronous on `stream`, stateless and re-entrant.  Pointers are borrowed for
+ * the duration of the launch; nothing is allocated or retained, except where a `workspace`
+ * argument is documented.  No exceptions cross the boundary: the return value is PXF_OK or a
+ * negative PXF_E* code.  Physics failures stay IN BAND exactly as in the reference (zeroed
+ * direction cosines, NaN, ...), see DESIGN.md.
+ *
+ * Arithmetic is fp64 throughout, compiled without FMA contraction, in the reference's operation
+ * order, so flat/reflect/transform/conic/Wolter results are bit-identical to the x86 reference.
+ */
+#ifndef PXF_H
+#define PXF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXF_ABI_VERSION 1
+
+#define PXF_OK 0
+#define PXF_EINVAL (-1)   /* NULL column, negative num, bad order table, ... */
+#define PXF_EHIP (-2)     /* a HIP runtime call failed; see pxf_last_hip_error() */
+#define PXF_ENODEV (-3)   /* no gfx950 device / code object not loadable */
+#define PXF_ERANGE (-4)   /* parameter outside the supported range (e.g. Zernike order > 15) */
+
+typedef void *pxf_stream_t; /* hipStream_t */
+
+int pxf_abi_version(void);
+const char *pxf_strerror(int code);
+int pxf_last_hip_error(void); /* hipError_t of the last failing HIP call on this thread */
+
+/* ---- surfacesf.f95 --------------------------------------------------------------------- */
+
+/* flat(x,y,z,l,m,n,ux,uy,uz,num)            surfacesf.f95:4-29
+ * Propagate to z=0; normal (0,0,1).  The propagation distance is rounded to fp32 as in the
+ * reference (implicit REAL*4 `delta`). */
+int pxf_flat(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+             double *ux, double *uy, double *uz, int64_t num, const uint8_t *mask, pxf_stream_t stream);
+
+/* flatOPD(x,y,z,l,m,n,ux,uy,uz,opd,num,nr)  surfacesf.f95:32-53 */
+int pxf_flatopd(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                double *ux, double *uy, double *uz, double *opd, int64_t num, double nr,
+                const uint8_t *mask, pxf_stream_t stream);
+
+/* conic(x,y,z,l,m,n,ux,uy,uz,num,R,K)       surfacesf.f95:302-360 */
+int pxf_conic(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+              double *uy, double *uz, int64_t num, double R, double K, const uint8_t *mask,
+              pxf_stream_t stream);
+
+/* conicopd(opd,x,y,z,l,m,n,ux,uy,uz,num,R,K,nr)  surfacesf.f95:366-420 */
+int pxf_conicopd(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                 double *ux, double *uy, double *uz, int64_t num, double R, double K, double nr,
+                 const uint8_t *mask, pxf_stream_t stream);
+
+/* ---- woltsurf.f95 ---------------------------------------------------------------------- */
+
+/* Van Speybroeck constants p,d,e from (r0,z0,psi), woltsurf.f95:18-23, evaluated on the host
+ * with libm exactly as the reference does at the top of every Wolter routine. */
+void pxf_wolter_params(double r0, double z0, double psi, double *p, double *d, double *e);
+
+/* wolterprimary(x,...,uz,num,r0,z0,psi)      woltsurf.f95:7-54   (Newton, tol 1.e-8 fp32 literal) */
+int pxf_wolterprimary(double *x, double *y, double *z, const double *l, const double *m,
+                      const double *n, double *ux, double *uy, double *uz, int64_t num, double r0,
+                      double z0, double psi, const uint8_t *mask, pxf_stream_t stream);
+
+/* wolterprimaryopd(opd,x,...,uz,num,r0,z0,psi,nr)  woltsurf.f95:60-108 (tol 1.e-10) */
+int pxf_wolterprimaryopd(double *opd, double *x, double *y, double *z, const double *l,
+                         const double *m, const double *n, double *ux, double *uy, double *uz,
+                         int64_t num, double r0, double z0, double psi, double nr,
+                         const uint8_t *mask, pxf_stream_t stream);
+
+/* woltersecondary(x,...,uz,num,r0,z0,psi)    woltsurf.f95:114-161 */
+int pxf_woltersecondary(double *x, double *y, double *z, const double *l, const double *m,
+                        const double *n, double *ux, double *uy, double *uz, int64_t num, double r0,
+                        double z0, double psi, const uint8_t *mask, pxf_stream_t stream);
+
+/* ---- zernsurf.f95 (+ zernset, specialFunctions.f95:142-232) ------------------------------- */
+
+/* tracezern(x,...,uz,num,coeff,rorder,aorder,arrsize,rad)   zernsurf.f95:8-101
+ * coeff/rorder/aorder are HOST arrays of length arrsize (they are folded on the host into a
+ * per-(n,|m|) table that the kernel stages in LDS).  aorder<0 -> sin, >0 -> cos, 0 -> radial
+ * term.  Orders up to n=15 are supported (PXF_ERANGE beyond). */
+int pxf_tracezern(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                  double *ux, double *uy, double *uz, int64_t num, const double *coeff,
+                  const int32_t *rorder, const int32_t *aorder, int32_t arrsize, double rad,
+                  const uint8_t *mask, pxf_stream_t stream);
+
+/* tracezernOPD(opd,x,...,uz,num,coeff,rorder,aorder,arrsize,rad,nr)   zernsurf.f95:108-203 */
+int pxf_tracezernopd(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+                     const double *n, double *ux, double *uy, double *uz, int64_t num,
+                     const double *coeff, const int32_t *rorder, const int32_t *aorder,
+                     int32_t arrsize, double rad, double nr, const uint8_t *mask, pxf_stream_t stream);
+
+/* ---- transformationsf.f95 -------------------------------------------------------------- */
+
+/* transform(x,...,uz,num,tx,ty,tz,rx,ry,rz)  transformationsf.f95:134-163
+ * p += t, then Rx(rx) Ry(ry) Rz(rz) on position, direction and normal.  (The Python wrapper
+ * negates all six parameters before this call, transformations.py:29.) */
+int pxf_transform(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+                  double *uy, double *uz, int64_t num, double tx, double ty, double tz, double rx,
+                  double ry, double rz, const uint8_t *mask, pxf_stream_t stream);
+
+/* itransform(...)                            transformationsf.f95:168-201 */
+int pxf_itransform(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+                   double *uy, double *uz, int64_t num, double tx, double ty, double tz, double rx,
+                   double ry, double rz, const uint8_t *mask, pxf_stream_t stream);
+
+/* reflect(l,m,n,ux,uy,uz,num)                transformationsf.f95:60-79 */
+int pxf_reflect(double *l, double *m, double *n, const double *ux, const double *uy,
+                const double *uz, int64_t num, const uint8_t *mask, pxf_stream_t stream);
+
+/* radgrat(x,y,l,m,n,wave,num,dpermm,order)   transformationsf.f95:205-238  (scalar wavelength;
+ * output sign of n from sign(n); evanescent -> NaN; pi is the reference's fp32 acos(-1.)) */
+int pxf_radgrat(const double *x, const double *y, double *l, double *m, double *n, double wave,
+                int64_t num, double dpermm, double order, const uint8_t *mask, pxf_stream_t stream);
+
+/* radgratW(x,y,l,m,n,wave,num,dpermm,order)  transformationsf.f95:242-272  (per-ray wavelength,
+ * device column; output sign of n from sign(y)) */
+int pxf_radgratw(const double *x, const double *y, double *l, double *m, double *n,
+                 const double *wave, int64_t num, double dpermm, double order, const uint8_t *mask,
+                 pxf_stream_t stream);
+
+/* ---- transformations.py host-side helpers that touch every ray ----------------------------- */
+
+/* applyT(rays,coords,inverse)                transformations.py:257-280
+ * Out-of-place: positions through the 4x4 `mpos` (rotation+translation, w=1), direction cosines
+ * and normals through the 4x4 `mdir` (rotation only).  Matrices are HOST row-major double[16].
+ * Replaces three dense np.dot(4x4, 4xN) products; K=4 is far too thin for MFMA. */
+int pxf_applyt(const double *x, const double *y, const double *z, const double *l, const double *m,
+               const double *n, const double *ux, const double *uy, const double *uz, double *ox,
+               double *oy, double *oz, double *ol, double *om, double *on, double *oux, double *ouy,
+               double *ouz, int64_t num, const double *mpos, const double *mdir, pxf_stream_t stream);
+
+/* applyTPos(x,y,z,coords,inverse)            transformations.py:282-289 */
+int pxf_applytpos(const double *x, const double *y, const double *z, double *ox, double *oy,
+                  double *oz, int64_t num, const double *mpos, pxf_stream_t stream);
+
+/* pointTo(rays,x0,y0,z0,reverse)             transformations.py:91-100 */
+int pxf_pointto(const double *x, const double *y, const double *z, double *l, double *m, double *n,
+                int64_t num, double x0, double y0, double z0, double reverse, pxf_stream_t stream);
+
+/* vignette(rays,ind)                         transformations.py:214-225
+ * Stable stream compaction (wavefront ballot + prefix sums).  Three steps:
+ *   pxf_vignette_mask     default predicate  l^2+m^2+n^2 > .1  -> uint8 mask (NaN -> dropped)
+ *   pxf_compact_scan      per-tile counts + exclusive scan into `workspace`; total -> *total_dev
+ *   pxf_compact_scatter   out[c][rank(i)] = in[c][i] for every kept ray, all columns at once
+ * `workspace` is caller-owned device memory of pxf_compact_workspace_bytes(num) bytes.
+ * `in_cols` / `out_cols` are HOST arrays of `ncols` (<= 16) device pointers. */
+size_t pxf_compact_workspace_bytes(int64_t num);
+int pxf_vignette_mask(const double *l, const double *m, const double *n, int64_t num,
+                      uint8_t *mask_out, pxf_stream_t stream);
+int pxf_compact_scan(const uint8_t *mask, int64_t num, void *workspace, int64_t *total_dev,
+                     pxf_stream_t stream);
+int pxf_compact_scatter(const double *const *in_cols, double *const *out_cols, int32_t ncols,
+                        int64_t num, const uint8_t *mask, const void *workspace, pxf_stream_t stream);
+/* rays[i][ind] with an integer index array (any order, repeats allowed, negatives wrap) */
+int pxf_gather(const double *const *in_cols, double *const *out_cols, int32_t ncols,
+               const int64_t *index, int64_t nidx, int64_t num, pxf_stream_t stream);
+/* ind (index array) -> uint8 mask of length num for the in-place `ind=` paths */
+int pxf_mask_from_index(const int64_t *index, int64_t nidx, int64_t num, uint8_t *mask_out,
+                        pxf_stream_t stream);
+
+/* ---- analyses.py reductions (focal-plane metrics) --------------------------------------------- */
+
+/* One pass, deterministic two-level tree (no atomics).  out_dev[PXF_NMOM] (device) receives
+ *   [0] S w   [1] S w x   [2] S w y   [3] S w l/n   [4] S w m/n   [5] S w x l/n   [6] S w y m/n
+ *   [7] S w (l/n)^2   [8] S w (m/n)^2   [9] S w l   [10] S w m   [11] S w n
+ * from which centroid (analyses.py:16-22), analyticImagePlane/X/Y (:118-155) and steerX/Y
+ * (transformations.py:79-89) follow.  w==NULL means unit weights.  l,m,n may be NULL (then
+ * only [0..2] are meaningful).  `workspace`: pxf_reduce_workspace_bytes() bytes. */
+#define PXF_NMOM 12
+size_t pxf_reduce_workspace_bytes(void);
+int pxf_moments(const double *x, const double *y, const double *l, const double *m, const double *n,
+                const double *w, int64_t num, double *out_dev, void *workspace, pxf_stream_t stream);
+/* Second pass about a centre: out_dev[4] = [S w, S w ((x-cx)^2+(y-cy)^2), S w (x-cx)^2, S w (y-cy)^2]
+ * -> rmsCentroid / rmsX / rmsY (analyses.py:24-58). */
+int pxf_central_moments(const double *x, const double *y, const double *w, int64_t num, double cx,
+                        double cy, double *out_dev, void *workspace, pxf_stream_t stream);
+
+/* ---- sources.py on the device ------------------------------------------------------------------ */
+
+/* Counter-based Philox4x32-10 keyed on (seed, first_index + i): the bundle is a pure function of
+ * the GLOBAL ray index, so a sharded run reproduces the single-GPU bundle exactly.  (The
+ * reference draws from NumPy's global MT19937 state, sources.py:40-41; the Python layer keeps
+ * that bit-exact host path as the default and offers this one for bundles too large for it.)
+ * cols = the ten columns in bundle order opd,x,y,z,l,m,n,ux,uy,uz (HOST array of device ptrs). */
+#define PXF_SRC_POINTSOURCE 0  /* p0 = ang                         sources.py:20-53   */
+#define PXF_SRC_CIRCULARBEAM 1 /* p0 = rad                         sources.py:56-88   */
+#define PXF_SRC_ANNULUS 2      /* p0 = rin, p1 = rout, p3 = zhat   sources.py:91-127  */
+#define PXF_SRC_SUBANNULUS 3   /* p0 = rin, p1 = rout, p2 = dphi, p3 = zhat  sources.py:130-170 */
+#define PXF_SRC_RECTBEAM 4     /* p0 = xhalfwidth, p1 = yhalfwidth sources.py:348-377 */
+int pxf_source(int32_t kind, double *const *cols, int64_t num, double p0, double p1, double p2,
+               double p3, uint64_t seed, uint64_t first_index, pxf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PXF_H */

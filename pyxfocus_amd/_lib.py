@@ -1,0 +1,92 @@
+"""ctypes binding of libpxf_hip.so (include/pxf.h) -- the only way the Python layer computes.
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this raises.  The
+library is built in-tree by ``__graft_entry__.build()`` / ``make -C pyxfocus_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must load first: libpxf_hip.so binds to the HIP runtime torch loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpxf_hip.so")
+
+PXF_NMOM = 12
+SRC_KINDS = {"pointsource": 0, "circularbeam": 1, "annulus": 2, "subannulus": 3, "rectbeam": 4}
+
+_P = C.c_void_p          # device pointer (tensor.data_ptr()) or NULL
+_d, _i64, _i32, _u64 = C.c_double, C.c_int64, C.c_int32, C.c_uint64
+_DP = C.POINTER(C.c_double)   # HOST double array
+_IP = C.POINTER(C.c_int32)    # HOST int32 array
+_PP = C.POINTER(C.c_void_p)   # HOST array of device pointers
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+_SIGS = {
+    "pxf_abi_version": [],
+    "pxf_strerror": [C.c_int],
+    "pxf_last_hip_error": [],
+    "pxf_flat": [_P] * 9 + [_i64, _P, _P],
+    "pxf_flatopd": [_P] * 10 + [_i64, _d, _P, _P],
+    "pxf_conic": [_P] * 9 + [_i64, _d, _d, _P, _P],
+    "pxf_conicopd": [_P] * 10 + [_i64, _d, _d, _d, _P, _P],
+    "pxf_wolter_params": [_d, _d, _d, _DP, _DP, _DP],
+    "pxf_wolterprimary": [_P] * 9 + [_i64, _d, _d, _d, _P, _P],
+    "pxf_wolterprimaryopd": [_P] * 10 + [_i64, _d, _d, _d, _d, _P, _P],
+    "pxf_woltersecondary": [_P] * 9 + [_i64, _d, _d, _d, _P, _P],
+    "pxf_tracezern": [_P] * 9 + [_i64, _DP, _IP, _IP, _i32, _d, _P, _P],
+    "pxf_tracezernopd": [_P] * 10 + [_i64, _DP, _IP, _IP, _i32, _d, _d, _P, _P],
+    "pxf_transform": [_P] * 9 + [_i64] + [_d] * 6 + [_P, _P],
+    "pxf_itransform": [_P] * 9 + [_i64] + [_d] * 6 + [_P, _P],
+    "pxf_reflect": [_P] * 6 + [_i64, _P, _P],
+    "pxf_radgrat": [_P] * 5 + [_d, _i64, _d, _d, _P, _P],
+    "pxf_radgratw": [_P] * 6 + [_i64, _d, _d, _P, _P],
+    "pxf_applyt": [_P] * 18 + [_i64, _DP, _DP, _P],
+    "pxf_applytpos": [_P] * 6 + [_i64, _DP, _P],
+    "pxf_pointto": [_P] * 6 + [_i64, _d, _d, _d, _d, _P],
+    "pxf_compact_workspace_bytes": [_i64],
+    "pxf_vignette_mask": [_P] * 3 + [_i64, _P, _P],
+    "pxf_compact_scan": [_P, _i64, _P, _P, _P],
+    "pxf_compact_scatter": [_PP, _PP, _i32, _i64, _P, _P, _P],
+    "pxf_gather": [_PP, _PP, _i32, _P, _i64, _i64, _P],
+    "pxf_mask_from_index": [_P, _i64, _i64, _P, _P],
+    "pxf_reduce_workspace_bytes": [],
+    "pxf_moments": [_P] * 6 + [_i64, _P, _P, _P],
+    "pxf_central_moments": [_P] * 3 + [_i64, _d, _d, _P, _P, _P],
+    "pxf_source": [_i32, _PP, _i64, _d, _d, _d, _d, _u64, _u64, _P],
+}
+_RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,
+            "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class PxfError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PxfError(
+                "pyxfocus_amd: %s not found -- the HIP extension is not built "
+                "(run __graft_entry__.build() or `make -C pyxfocus_amd/csrc`). "
+                "There is no CPU fallback." % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, argtypes in _SIGS.items():
+            f = getattr(h, name)      # AttributeError here = header/library mismatch: fail loudly
+            f.argtypes = argtypes
+            f.restype = _RESTYPE.get(name, C.c_int)
+        if h.pxf_abi_version() != 1:
+            raise PxfError("libpxf_hip.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        h = lib()
+        raise PxfError("%s failed: %s (code %d, hipError %d)" % (
+            what, h.pxf_strerror(code).decode(), code, h.pxf_last_hip_error()))

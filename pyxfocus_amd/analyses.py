@@ -1,0 +1,174 @@
+"""Drop-in for the focal-plane part of PyXFocus ``analyses.py`` (analyses.py:16-97, 118-187).
+
+All per-ray sums are one fused HIP reduction (pxf_moments / pxf_central_moments); the scalar
+algebra that turns sums into centroid / RMS / best-focus shift is the reference's, evaluated on
+the host.  Functions return Python floats (this is the point where the stream is synchronised).
+``weights`` may be None, a NumPy array or a tensor with one entry per ray.
+
+In a sharded (multi-GPU) run pass ``group=`` (a torch.distributed process group, or True for the
+default group): the twelve partial sums are all-reduced over RCCL before the scalar algebra, so
+every rank returns the global metric without gathering any ray.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, native
+
+_ws_cache = {}
+
+
+def _workspace(dev):
+    key = (dev.type, dev.index)
+    if key not in _ws_cache:
+        nbytes = _lib.lib().pxf_reduce_workspace_bytes()
+        _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return _ws_cache[key]
+
+
+def _weights(weights, num, dev):
+    if weights is None:
+        return None
+    w = weights if isinstance(weights, torch.Tensor) else torch.as_tensor(np.asarray(weights, dtype=np.float64))
+    w = w.to(device=dev, dtype=torch.float64).contiguous()
+    if w.dim() != 1 or w.shape[0] != num:
+        raise ValueError("weights must have one entry per ray")
+    return w
+
+
+def _allreduce(out, group):
+    if group is None or group is False:
+        return out
+    import torch.distributed as dist
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=None if group is True else group)
+    return out
+
+
+def _moments(rays, weights, dirs=True, group=None):
+    """The twelve weighted sums of include/pxf.h (PXF_NMOM) as a Python list of floats."""
+    x, y = rays[1], rays[2]
+    cols = (x, y) + ((rays[4], rays[5], rays[6]) if dirs else ())
+    num, dev = native._check_cols(cols, "analyses")
+    w = _weights(weights, num, dev)
+    out = torch.zeros(_lib.PXF_NMOM, dtype=torch.float64, device=dev)
+    p = [c.data_ptr() for c in cols] + [None] * (5 - len(cols))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_moments(*p, None if w is None else w.data_ptr(), num, out.data_ptr(),
+                                    _workspace(dev).data_ptr(), native._stream(dev))
+    _lib.check(rc, "pxf_moments")
+    return _allreduce(out, group).tolist()
+
+
+def _central(rays, weights, cx, cy, group=None):
+    x, y = rays[1], rays[2]
+    num, dev = native._check_cols((x, y), "analyses")
+    w = _weights(weights, num, dev)
+    out = torch.zeros(4, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_central_moments(x.data_ptr(), y.data_ptr(), None if w is None else w.data_ptr(),
+                                            num, float(cx), float(cy), out.data_ptr(),
+                                            _workspace(dev).data_ptr(), native._stream(dev))
+    _lib.check(rc, "pxf_central_moments")
+    return _allreduce(out, group).tolist()
+
+
+def centroid(rays, weights=None, group=None):
+    """Centroid of the rays in the xy plane (analyses.py:16-22)."""
+    s = _moments(rays, weights, dirs=False, group=group)
+    return s[1] / s[0], s[2] / s[0]
+
+
+def rmsCentroid(rays, weights=None, group=None):
+    """RMS of rays from centroid in the xy plane (analyses.py:24-30) -- the spot-size metric."""
+    cx, cy = centroid(rays, weights=weights, group=group)
+    s = _central(rays, weights, cx, cy, group=group)
+    return math.sqrt(s[1] / s[0])
+
+
+def rmsX(rays, weights=None, group=None):
+    """RMS from centroid in the X direction (analyses.py:46-51)."""
+    cx, cy = centroid(rays, weights=weights, group=group)
+    s = _central(rays, weights, cx, cy, group=group)
+    return math.sqrt(s[2] / s[0])
+
+
+def rmsY(rays, weights=None, group=None):
+    """RMS from centroid in the Y direction (analyses.py:53-58)."""
+    cx, cy = centroid(rays, weights=weights, group=group)
+    s = _central(rays, weights, cx, cy, group=group)
+    return math.sqrt(s[3] / s[0])
+
+
+def rho(rays, weights=None, cent=False):
+    """Distance from the centroid (cent=True) or the origin for all rays (analyses.py:60-71)."""
+    x, y = rays[1:3]
+    cx, cy = centroid(rays, weights=weights) if cent is True else (0, 0)
+    return torch.sqrt((x - cx) ** 2 + (y - cy) ** 2)
+
+
+def rhocdf(rays, weights=None, cent=True):
+    """Radial CDF of the ray distribution (analyses.py:73-86)."""
+    r = rho(rays, weights=weights, cent=cent)
+    w = torch.ones_like(r) if weights is None else _weights(weights, r.shape[0], r.device)
+    r, ind = torch.sort(r, stable=True)
+    cdf = torch.cumsum(w[ind], 0)
+    return r, cdf / cdf.max()
+
+
+def hpd(rays, weights=None, cent=True):
+    """HPD: twice the median radius from the centroid; weighted: the 25-75 % CDF span
+    (analyses.py:88-97; like the reference, `cent` is ignored and the centroid is always used)."""
+    if weights is not None:
+        r, cdf = rhocdf(rays, weights=weights, cent=True)
+        return float(r[torch.argmin(torch.abs(cdf - .75))] - r[torch.argmin(torch.abs(cdf - .25))])
+    r = rho(rays, weights=None, cent=True)
+    n = r.shape[0]
+    if n == 0:
+        return float("nan")
+    lo = torch.kthvalue(r, (n - 1) // 2 + 1).values      # np.median: mean of the two middle values
+    hi = torch.kthvalue(r, n // 2 + 1).values
+    return float((lo + hi) * .5) * 2.
+
+
+def analyticImagePlane(rays, weights=None, group=None):
+    """Best-focus shift by the analytic method of Ron Elsner's paper (analyses.py:118-133)."""
+    s = _moments(rays, weights, group=group)
+    W = s[0]
+    bx = s[5] / W - (s[1] / W) * (s[3] / W)
+    ax = s[7] / W - (s[3] / W) ** 2
+    by = s[6] / W - (s[2] / W) * (s[4] / W)
+    ay = s[8] / W - (s[4] / W) ** 2
+    return -(bx + by) / (ax + ay)
+
+
+def analyticYPlane(rays, weights=None, group=None):
+    """analyses.py:135-144"""
+    s = _moments(rays, weights, group=group)
+    W = s[0]
+    by = s[6] / W - (s[2] / W) * (s[4] / W)
+    ay = s[8] / W - (s[4] / W) ** 2
+    return -by / ay
+
+
+def analyticXPlane(rays, weights=None, group=None):
+    """analyses.py:146-155"""
+    s = _moments(rays, weights, group=group)
+    W = s[0]
+    bx = s[5] / W - (s[1] / W) * (s[3] / W)
+    ax = s[7] / W - (s[3] / W) ** 2
+    return -bx / ax
+
+
+def indAngle(rays, ind=None, normal=None):
+    """Incidence angle of the rays with the current (or a given) surface normal (analyses.py:164-182)."""
+    sel = slice(None) if ind is None else ind
+    l, m, n = rays[4][sel], rays[5][sel], rays[6][sel]
+    if normal is None:
+        return torch.arccos(l * rays[7][sel] + m * rays[8][sel] + n * rays[9][sel])
+    return torch.arccos(normal[0] * l + normal[1] * m + normal[2] * n)
+
+
+def grazeAngle(rays, ind=None):
+    """Graze angle of the rays with the current surface normal (analyses.py:184-187)."""
+    return math.pi / 2 - indAngle(rays, ind=ind)

@@ -1,0 +1,153 @@
+// pxf_sources.hip -- sources.pointsource / circularbeam / annulus / subannulus / rectbeam on the device
+// (sources.py:20-53, 56-88, 91-127, 130-170, 348-377).
+//
+// The reference draws `rho` then `theta` as two np.random.rand(num) vectors from NumPy's global
+// MT19937 state -- inherently serial and host-only; 1e9 rays would take minutes and 80 GB of PCIe
+// traffic.  Here each ray draws from a COUNTER-BASED generator, Philox4x32-10 (Salmon et al.,
+// SC'11), keyed on (seed) with counter = GLOBAL ray index: no state, no ordering, and a bundle
+// sharded over N GPUs is bit-identical to the single-GPU bundle.  The distributions are the
+// reference's (same formulas, same 53-bit uniforms in [0,1)); the random STREAM differs, so
+// parity with a seeded NumPy run is distributional, not per-ray (the Python layer keeps the
+// NumPy path for per-ray reproducibility at host-sized bundles).
+#include <math.h>
+
+#include "pxf_kernel.h"
+
+namespace pxf {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0;
+        c[1] = lo1;
+        c[2] = n2;
+        c[3] = lo0;
+        k0 += W0;
+        k1 += W1;
+    }
+}
+
+// two 53-bit uniforms in [0,1) per global ray index (same construction as NumPy's random_sample)
+__device__ __forceinline__ void uniform2(uint64_t seed, uint64_t index, double &u1, double &u2)
+{
+    uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), 0u, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t a = ((uint64_t)c[0] << 32) | c[1], b = ((uint64_t)c[2] << 32) | c[3];
+    u1 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+    u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct SrcParams {
+    double p0, p1, p2, p3;
+    uint64_t seed, first;
+};
+
+template <int KIND>
+__device__ __forceinline__ void make_ray(const SrcParams &q, uint64_t gidx, double (&c)[10])
+{
+    double u1, u2;
+    uniform2(q.seed, gidx, u1, u2);
+#pragma unroll
+    for (int k = 0; k < 10; k++) c[k] = 0.;
+    const double twopi = 2 * 3.141592653589793;
+    if (KIND == PXF_SRC_POINTSOURCE) {  // sources.py:39-44
+        const double rho = sqrt(u1) * sin(q.p0);
+        const double th = u2 * twopi;
+        c[L] = rho * cos(th);
+        c[M] = rho * sin(th);
+        c[N] = sqrt(1. - c[L] * c[L] - c[M] * c[M]);
+    } else if (KIND == PXF_SRC_CIRCULARBEAM) {  // sources.py:74-81
+        const double rho = sqrt(u1) * q.p0;
+        const double th = u2 * twopi;
+        c[X] = rho * cos(th);
+        c[Y] = rho * sin(th);
+        c[N] = 1.;
+    } else if (KIND == PXF_SRC_ANNULUS) {  // sources.py:114-121
+        const double rho = sqrt(q.p0 * q.p0 + u1 * (q.p1 * q.p1 - q.p0 * q.p0));
+        const double th = u2 * twopi;
+        c[X] = rho * cos(th);
+        c[Y] = rho * sin(th);
+        c[N] = q.p3;
+    } else if (KIND == PXF_SRC_SUBANNULUS) {  // sources.py:157-164
+        const double rho = sqrt(q.p0 * q.p0 + u1 * (q.p1 * q.p1 - q.p0 * q.p0));
+        const double th = u2 * q.p2 - q.p2 / 2.;
+        c[X] = rho * cos(th);
+        c[Y] = rho * sin(th);
+        c[N] = q.p3;
+    } else {  // PXF_SRC_RECTBEAM, sources.py:364-367
+        c[X] = (u1 - .5) * 2 * q.p0;
+        c[Y] = (u2 - .5) * 2 * q.p1;
+        c[N] = 1.;
+    }
+}
+
+template <int KIND, int V>
+__global__ __launch_bounds__(kBlock) void source_kernel(Cols cols, int64_t first, int64_t nvec, SrcParams q)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const int64_t vv = first + v;
+        double r[V][10];
+#pragma unroll
+        for (int k = 0; k < V; k++) make_ray<KIND>(q, q.first + (uint64_t)(vv * V + k), r[k]);
+#pragma unroll
+        for (int col = 0; col < 10; col++) {
+            double t[V];
+            bool w[V];
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                t[k] = r[k][col];
+                w[k] = true;
+            }
+            store_col<V>(cols.p[col], vv, t, w);
+        }
+    }
+}
+
+template <int KIND>
+static void launch_kind(const Cols &c, bool aligned, int64_t num, const SrcParams &q, hipStream_t s)
+{
+    const int64_t nvec2 = aligned ? num / 2 : 0;
+    if (nvec2 > 0)
+        hipLaunchKernelGGL((source_kernel<KIND, 2>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0,
+                           nvec2, q);
+    const int64_t done = nvec2 * 2;
+    if (done < num)
+        hipLaunchKernelGGL((source_kernel<KIND, 1>), dim3(grid_for(num - done)), dim3(kBlock), 0, s, c, done,
+                           num - done, q);
+}
+
+}  // namespace pxf
+
+using namespace pxf;
+
+extern "C" int pxf_source(int32_t kind, double *const *cols, int64_t num, double p0, double p1, double p2,
+                          double p3, uint64_t seed, uint64_t first_index, pxf_stream_t stream)
+{
+    if (num < 0 || !cols) return PXF_EINVAL;
+    Cols c{};
+    bool aligned = true;
+    for (int k = 0; k < 10; k++) {
+        if (!cols[k]) return PXF_EINVAL;
+        c.p[k] = cols[k];
+        if ((uintptr_t)cols[k] & 15) aligned = false;
+    }
+    if (num == 0) return PXF_OK;
+    SrcParams q{p0, p1, p2, p3, seed, first_index};
+    hipStream_t s = (hipStream_t)stream;
+    switch (kind) {
+        case PXF_SRC_POINTSOURCE: launch_kind<PXF_SRC_POINTSOURCE>(c, aligned, num, q, s); break;
+        case PXF_SRC_CIRCULARBEAM: launch_kind<PXF_SRC_CIRCULARBEAM>(c, aligned, num, q, s); break;
+        case PXF_SRC_ANNULUS: launch_kind<PXF_SRC_ANNULUS>(c, aligned, num, q, s); break;
+        case PXF_SRC_SUBANNULUS: launch_kind<PXF_SRC_SUBANNULUS>(c, aligned, num, q, s); break;
+        case PXF_SRC_RECTBEAM: launch_kind<PXF_SRC_RECTBEAM>(c, aligned, num, q, s); break;
+        default: return PXF_EINVAL;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}

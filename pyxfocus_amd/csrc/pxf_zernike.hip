@@ -1,0 +1,265 @@
+// pxf_zernike.hip -- Newton trace to a Zernike sag surface: tracezern / tracezernOPD
+// (zernsurf.f95:8-101 / 108-203) with zernset (specialFunctions.f95:142-232) inlined.
+//
+// What the reference does per Newton step and per ray: two heap allocations, pow(rho,n),
+// atan2, and 3 x arrsize sin/cos(m*theta) calls (~3.1 us/ray for 36 terms on one CPU core).
+// What this kernel does instead (MI355X-first, fp64 VALU-bound, no transcendentals at all):
+//   * theta never materialises: cos(theta)=x/rho, sin(theta)=y/rho, and cos/sin(m*theta) come
+//     from the angle-addition recurrence (m <= 15);
+//   * rho'^n is a running product; the radial polynomials R_n^m, dR_n^m/drho' follow the
+//     REFERENCE's own downward q-recursion (specialFunctions.f95:187-199), whose coefficients
+//     h1,h2,h3 depend only on (n,m) and are compile-time constants of the fully unrolled body;
+//   * the user's (coeff, rorder, aorder) list is folded ON THE HOST into one (Ac, As) pair per
+//     (n,|m|) -- cos-type and sin-type amplitude including the sqrt(2(n+1)) normalisation (and
+//     the reference's single-precision sqrt(0.5) for m=0, specialFunctions.f95:225) -- and that
+//     table is staged in LDS once per workgroup; every lane reads the same address (broadcast);
+//   * one ray per thread (VALU-bound: wide loads buy nothing, fewer VGPRs do).
+// Parity is to a stated tolerance, not bitwise: summation order over terms, recurrences instead of
+// libm, and FMA contraction (this TU only) all differ from the reference at the 1e-16 level, and
+// the Newton iteration contracts those differences quadratically.  See DESIGN.md.
+#include <math.h>
+
+#include "pxf_kernel.h"
+
+namespace pxf {
+
+constexpr int kZernMaxN = 15;
+constexpr int zern_npairs(int nmax) { return ((nmax + 2) / 2) * ((nmax + 3) / 2); }  // #(n,m): n<=nmax
+// index of pair (n,m) (m same parity as n, 0<=m<=n) in the table: pairs of all smaller n, then m/2
+constexpr int zern_pair(int n, int m) { return zern_npairs(n - 1) + m / 2; }
+
+struct ZernTab {
+    double2 a[zern_npairs(kZernMaxN)];  // .x = Ac (cos-type, and m=0), .y = As (sin-type)
+};
+
+// q-recursion coefficients, specialFunctions.f95:195-197
+constexpr double zh3(double n, double m) { return -4 * (m + 2) * (m + 1) / (n + m + 2) / (n - m); }
+constexpr double zh2(double n, double m) { return zh3(n, m) * (n + m + 4) * (n - m - 2) / 4. / (m + 3) + (m + 2); }
+constexpr double zh1(double n, double m)
+{
+    return .5 * (m + 4) * (m + 3) - (m + 4) * zh2(n, m) + zh3(n, m) * (n + m + 6) * (n - m - 4) / 8.;
+}
+
+template <int NMAX>
+struct ZernOp {
+    static constexpr int MAXV = 1;
+    static constexpr unsigned RD = POS | DIR | B(OPD);  // opd column only touched when has_opd
+    static constexpr unsigned WR = POS | NRM | B(OPD);
+    static constexpr int NP = zern_npairs(NMAX);
+    double2 tab_arg[zern_npairs(NMAX)];  // folded table, by value in the kernel-argument segment
+    double rad, nr;
+    int has_opd;
+
+    __device__ __forceinline__ double2 *lds() const
+    {
+        __shared__ double2 s_tab[zern_npairs(NMAX)];
+        return s_tab;
+    }
+
+    __device__ __forceinline__ void prologue() const
+    {
+        double2 *s = lds();
+        for (int i = threadIdx.x; i < NP; i += kBlock) s[i] = tab_arg[i];
+        __syncthreads();
+    }
+
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+        static_assert(V == 1, "Zernike kernel is one ray per thread");
+        const double2 *__restrict__ tab = lds();
+        double *c = r[0].c;
+        const double l = c[L], m = c[M], n = c[N];
+        double x = c[X], y = c[Y], z = c[Z];
+        double t = 0., Fx = 0., Fy = 0., Fz = 0.;
+        bool act = sel[0];
+        for (int it = 0; act && it < kNewtonCap; it++) {
+            const double rho = sqrt(x * x + y * y);
+            const double ct = x / rho, st = y / rho;  // cos/sin(atan2(y,x)); rho==0 -> NaN as the reference
+            const double rp = rho / rad;
+            const double irp2 = 1. / (rp * rp), irp3 = irp2 / rp;
+            double cm[NMAX + 1], sm[NMAX + 1], pw[NMAX + 1];
+            cm[0] = 1.;
+            sm[0] = 0.;
+            pw[0] = 1.;
+#pragma unroll
+            for (int k = 1; k <= NMAX; k++) {
+                cm[k] = cm[k - 1] * ct - sm[k - 1] * st;
+                sm[k] = sm[k - 1] * ct + cm[k - 1] * st;
+                pw[k] = pw[k - 1] * rp;
+            }
+            double S = 0., Sr = 0., St = 0.;
+#pragma unroll
+            for (int nn = 0; nn <= NMAX; nn++) {
+                double R2 = 0., Rp2 = 0., R4 = 0., Rp4 = 0.;  // R_n^{m+2}, R_n^{m+4} of the chain
+#pragma unroll
+                for (int mm = nn; mm >= 0; mm -= 2) {
+                    double R, Rp;
+                    if (mm == nn) {
+                        R = pw[nn];
+                        Rp = nn == 0 ? 0. : (double)nn * pw[nn > 0 ? nn - 1 : 0];
+                    } else if (mm == nn - 2) {
+                        R = (double)nn * pw[nn] - (double)(nn - 1) * pw[nn - 2];
+                        const double dnn = (double)nn * pw[nn - 1];
+                        const double dn2 = nn - 2 == 0 ? 0. : (double)(nn - 2) * pw[nn > 2 ? nn - 3 : 0];
+                        Rp = (double)nn * dnn - (double)(nn - 1) * dn2;
+                    } else {
+                        const double h3 = zh3(nn, mm), h2 = zh2(nn, mm), h1 = zh1(nn, mm);
+                        const double g = h2 + h3 * irp2;
+                        R = h1 * R4 + g * R2;
+                        Rp = h1 * Rp4 + g * Rp2 - 2 * h3 * irp3 * R2;
+                    }
+                    R4 = R2;
+                    Rp4 = Rp2;
+                    R2 = R;
+                    Rp2 = Rp;
+                    const double2 a = tab[zern_pair(nn, mm)];
+                    const double t1 = a.x * cm[mm] + a.y * sm[mm];
+                    S += R * t1;
+                    Sr += Rp * t1;
+                    if (mm > 0) St += R * ((double)mm * (a.y * cm[mm] - a.x * sm[mm]));
+                }
+            }
+            const double F = z - S;
+            const double Frho = -Sr / rad;
+            const double Ftheta = -St;
+            Fx = ct * Frho + (-st) * Ftheta / rho;
+            Fy = st * Frho + ct * Ftheta / rho;
+            Fz = 1.;
+            const double Fp = Fx * l + Fy * m + Fz * n;
+            const double delta = -F / Fp;
+            x = x + l * delta;
+            y = y + m * delta;
+            z = z + n * delta;
+            t = t + delta;
+            act = fabs(delta) > PXF_TOL_1EM10;
+        }
+        const double Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+        c[X] = x;
+        c[Y] = y;
+        c[Z] = z;
+        c[UX] = Fx / Fp;
+        c[UY] = Fy / Fp;
+        c[UZ] = Fz / Fp;
+        c[OPD] = c[OPD] + t * nr;  // zernsurf.f95:199 -- once, from the accumulated path length
+        wm[0] = POS | NRM | (has_opd ? B(OPD) : 0u);
+    }
+};
+
+// The opd column is optional: the generic kernel loads every RD column, so the plain variant
+// points OPD at x (a harmless extra 8 B/ray read would be wasteful -- instead use a distinct Op
+// without OPD).  Two thin wrappers select the column sets at compile time.
+template <int NMAX, bool WOPD>
+struct ZernOpSel : ZernOp<NMAX> {
+    static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
+    static constexpr unsigned WR = POS | NRM | (WOPD ? B(OPD) : 0u);
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+        if (!WOPD) r[0].c[OPD] = 0.;
+        ZernOp<NMAX>::template apply<V>(r, sel, wm);
+    }
+};
+
+// ---- host: fold (coeff, rorder, aorder) into the (n,|m|) table ----------------------------
+static int fold_table(const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
+                      ZernTab &tab, int &nmax)
+{
+    if (arrsize < 0 || (arrsize > 0 && (!coeff || !rorder || !aorder))) return PXF_EINVAL;
+    for (auto &a : tab.a) a = make_double2(0., 0.);
+    nmax = 0;
+    const double sqrt_half_f32 = (double)sqrtf(0.5f);  // specialFunctions.f95:225: REAL*4 sqrt(0.5)
+    for (int i = 0; i < arrsize; i++) {
+        const int n = rorder[i], mm = aorder[i], m = mm < 0 ? -mm : mm;
+        if (n < 0 || m > n || ((n - m) & 1)) return PXF_EINVAL;  // the reference reads garbage here
+        if (n > kZernMaxN) return PXF_ERANGE;
+        if (n > nmax) nmax = n;
+        const double norm = sqrt(2. * (n + 1));
+        double2 &a = tab.a[zern_pair(n, m)];
+        if (mm < 0)
+            a.y += coeff[i] * norm;
+        else if (mm > 0)
+            a.x += coeff[i] * norm;
+        else
+            a.x += coeff[i] * (norm * sqrt_half_f32);
+    }
+    return PXF_OK;
+}
+
+template <int NMAX, bool WOPD>
+static int launch_nmax(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream,
+                       const ZernTab &tab, double rad, double nr)
+{
+    ZernOpSel<NMAX, WOPD> op;
+    for (int i = 0; i < zern_npairs(NMAX); i++) op.tab_arg[i] = tab.a[i];
+    op.rad = rad;
+    op.nr = nr;
+    op.has_opd = WOPD;
+    return launch_rays(c, num, mask, stream, op);
+}
+
+template <bool WOPD, int NMAX = kZernMaxN>
+static int dispatch_nmax(int nmax, const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream,
+                         const ZernTab &tab, double rad, double nr)
+{
+    if constexpr (NMAX < 1) {
+        return launch_nmax<1, WOPD>(c, num, mask, stream, tab, rad, nr);
+    } else {
+        if (nmax >= NMAX) return launch_nmax<NMAX, WOPD>(c, num, mask, stream, tab, rad, nr);
+        return dispatch_nmax<WOPD, NMAX - 1>(nmax, c, num, mask, stream, tab, rad, nr);
+    }
+}
+
+template <bool WOPD>
+static int run(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+               const double *n, double *ux, double *uy, double *uz, int64_t num, const double *coeff,
+               const int32_t *rorder, const int32_t *aorder, int32_t arrsize, double rad, double nr,
+               const uint8_t *mask, pxf_stream_t stream)
+{
+    ZernTab tab;
+    int nmax = 0;
+    int rc = fold_table(coeff, rorder, aorder, arrsize, tab, nmax);
+    if (rc != PXF_OK) return rc;
+    if (num < 0) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
+    Cols c{};
+    c.p[OPD] = opd;
+    c.p[X] = x;
+    c.p[Y] = y;
+    c.p[Z] = z;
+    c.p[L] = const_cast<double *>(l);
+    c.p[M] = const_cast<double *>(m);
+    c.p[N] = const_cast<double *>(n);
+    c.p[UX] = ux;
+    c.p[UY] = uy;
+    c.p[UZ] = uz;
+    // the folded table travels by value in the kernel arguments (<= 1152 B) and is staged into LDS
+    // by each workgroup's prologue: no allocation, no copy, nothing to keep alive, graph-capturable
+    return dispatch_nmax<WOPD>(nmax, c, num, mask, stream, tab, rad, nr);
+}
+
+}  // namespace pxf
+
+using namespace pxf;
+
+extern "C" {
+
+int pxf_tracezern(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                  double *ux, double *uy, double *uz, int64_t num, const double *coeff,
+                  const int32_t *rorder, const int32_t *aorder, int32_t arrsize, double rad,
+                  const uint8_t *mask, pxf_stream_t stream)
+{
+    return run<false>(nullptr, x, y, z, l, m, n, ux, uy, uz, num, coeff, rorder, aorder, arrsize, rad, 0.,
+                      mask, stream);
+}
+
+int pxf_tracezernopd(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+                     const double *n, double *ux, double *uy, double *uz, int64_t num,
+                     const double *coeff, const int32_t *rorder, const int32_t *aorder,
+                     int32_t arrsize, double rad, double nr, const uint8_t *mask, pxf_stream_t stream)
+{
+    return run<true>(opd, x, y, z, l, m, n, ux, uy, uz, num, coeff, rorder, aorder, arrsize, rad, nr, mask,
+                     stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+"""f2py-shaped front end of the HIP library, on torch tensors.
+
+The four namespaces carry the names of the reference's f2py extension modules
+(``PyXFocus.surfacesf / woltsurf / zernsurf / transformationsf``, compiletrace.sh:1-6) and the same
+call signatures: SoA columns first, then scalars; columns are mutated in place;
+``num`` is implied by ``len(x)``.  Columns must be 1-D contiguous ``torch.float64`` tensors on
+one ROCm device (f2py raises for non-contiguous / wrong-dtype ``intent(inout)`` arrays; so do we).
+
+Extra keyword on every call: ``mask`` -- a ``torch.bool``/``uint8`` tensor of the same length; rays
+with mask 0 are left untouched (the reference wrappers' ``ind=`` path, done in-kernel).
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _check_cols(cols, what):
+    t0 = cols[0]
+    for t in cols:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s: ray columns must be torch tensors, got %s" % (what, type(t).__name__))
+        if t.dtype != torch.float64 or t.dim() != 1 or not t.is_contiguous():
+            raise TypeError("%s: ray columns must be 1-D contiguous float64 tensors" % what)
+        if not t.is_cuda:
+            raise TypeError("%s: ray columns must live on a ROCm device (no CPU path exists)" % what)
+        if t.device != t0.device:
+            raise ValueError("%s: ray columns live on different devices" % what)
+        if t.shape[0] != t0.shape[0]:
+            raise ValueError("%s: ray columns differ in length" % what)
+    return t0.shape[0], t0.device
+
+
+def _mask_ptr(mask, num, dev, what):
+    if mask is None:
+        return None
+    if not isinstance(mask, torch.Tensor) or mask.dtype not in (torch.bool, torch.uint8):
+        raise TypeError("%s: mask must be a torch.bool / torch.uint8 tensor" % what)
+    if mask.device != dev or mask.dim() != 1 or mask.shape[0] != num or not mask.is_contiguous():
+        raise ValueError("%s: mask must be a contiguous 1-D tensor of the rays' length and device" % what)
+    return mask.data_ptr()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _call(name, cols, tail, mask=None):
+    """cols -> device pointers, then num, then `tail` scalars, then mask, stream."""
+    num, dev = _check_cols(cols, name)
+    mp = _mask_ptr(mask, num, dev, name)
+    h = _lib.lib()
+    with torch.cuda.device(dev):
+        rc = getattr(h, name)(*[t.data_ptr() for t in cols], num, *tail, mp, _stream(dev))
+    _lib.check(rc, name)
+
+
+# ---- surfacesf ------------------------------------------------------------------------------
+def flat(x, y, z, l, m, n, ux, uy, uz, mask=None):
+    _call("pxf_flat", (x, y, z, l, m, n, ux, uy, uz), (), mask)
+
+
+def flatopd(x, y, z, l, m, n, ux, uy, uz, opd, nr, mask=None):
+    _call("pxf_flatopd", (x, y, z, l, m, n, ux, uy, uz, opd), (float(nr),), mask)
+
+
+def conic(x, y, z, l, m, n, ux, uy, uz, R, K, mask=None):
+    _call("pxf_conic", (x, y, z, l, m, n, ux, uy, uz), (float(R), float(K)), mask)
+
+
+def conicopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, nr, mask=None):
+    _call("pxf_conicopd", (opd, x, y, z, l, m, n, ux, uy, uz), (float(R), float(K), float(nr)), mask)
+
+
+# ---- woltsurf -------------------------------------------------------------------------------
+def wolterprimary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, mask=None):
+    _call("pxf_wolterprimary", (x, y, z, l, m, n, ux, uy, uz), (float(r0), float(z0), float(psi)), mask)
+
+
+def wolterprimaryopd(opd, x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, nr, mask=None):
+    _call("pxf_wolterprimaryopd", (opd, x, y, z, l, m, n, ux, uy, uz),
+          (float(r0), float(z0), float(psi), float(nr)), mask)
+
+
+def woltersecondary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, mask=None):
+    _call("pxf_woltersecondary", (x, y, z, l, m, n, ux, uy, uz), (float(r0), float(z0), float(psi)), mask)
+
+
+def wolter_params(r0, z0, psi=1.):
+    o = [C.c_double() for _ in range(3)]
+    _lib.lib().pxf_wolter_params(float(r0), float(z0), float(psi), *[C.byref(v) for v in o])
+    return tuple(v.value for v in o)
+
+
+# ---- zernsurf -------------------------------------------------------------------------------
+def _zern_tables(coeff, rorder, aorder):
+    ck = np.ascontiguousarray(np.asarray(coeff if not isinstance(coeff, torch.Tensor) else coeff.cpu(),
+                                         dtype=np.float64))
+    rk = np.ascontiguousarray(np.asarray(rorder), dtype=np.int32)   # f2py casts int64 -> int32 silently
+    ak = np.ascontiguousarray(np.asarray(aorder), dtype=np.int32)
+    if not (ck.ndim == rk.ndim == ak.ndim == 1 and len(ck) == len(rk) == len(ak)):
+        raise ValueError("tracezern: coeff, rorder, aorder must be 1-D and of equal length")
+    return (ck, rk, ak, ck.ctypes.data_as(_lib._DP), rk.ctypes.data_as(_lib._IP), ak.ctypes.data_as(_lib._IP))
+
+
+def tracezern(x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, mask=None):
+    ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    _call("pxf_tracezern", (x, y, z, l, m, n, ux, uy, uz), (cp, rp, ap, len(ck), float(rad)), mask)
+
+
+def tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, nr, mask=None):
+    ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    _call("pxf_tracezernopd", (opd, x, y, z, l, m, n, ux, uy, uz),
+          (cp, rp, ap, len(ck), float(rad), float(nr)), mask)
+
+
+# ---- transformationsf -----------------------------------------------------------------------
+def transform(x, y, z, l, m, n, ux, uy, uz, tx, ty, tz, rx, ry, rz, mask=None):
+    _call("pxf_transform", (x, y, z, l, m, n, ux, uy, uz),
+          tuple(float(v) for v in (tx, ty, tz, rx, ry, rz)), mask)
+
+
+def itransform(x, y, z, l, m, n, ux, uy, uz, tx, ty, tz, rx, ry, rz, mask=None):
+    _call("pxf_itransform", (x, y, z, l, m, n, ux, uy, uz),
+          tuple(float(v) for v in (tx, ty, tz, rx, ry, rz)), mask)
+
+
+def reflect(l, m, n, ux, uy, uz, mask=None):
+    _call("pxf_reflect", (l, m, n, ux, uy, uz), (), mask)
+
+
+def radgrat(x, y, l, m, n, wave, dpermm, order, mask=None):
+    # argument order of the f2py signature: (x,y,l,m,n,wave,dpermm,order)
+    num, dev = _check_cols((x, y, l, m, n), "pxf_radgrat")
+    mp = _mask_ptr(mask, num, dev, "pxf_radgrat")
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_radgrat(x.data_ptr(), y.data_ptr(), l.data_ptr(), m.data_ptr(), n.data_ptr(),
+                                    float(wave), num, float(dpermm), float(order), mp, _stream(dev))
+    _lib.check(rc, "pxf_radgrat")
+
+
+def radgratw(x, y, l, m, n, wave, dpermm, order, mask=None):
+    _call("pxf_radgratw", (x, y, l, m, n, wave), (float(dpermm), float(order)), mask)
+
+
+surfacesf = SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd)
+woltsurf = SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
+                           woltersecondary=woltersecondary)
+zernsurf = SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd)
+transformationsf = SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
+                                   radgrat=radgrat, radgratw=radgratw)

@@ -1,0 +1,121 @@
+"""Drop-in for the hot-path part of PyXFocus ``surfaces.py`` on ROCm tensors.
+
+Same names, argument order and defaults as the reference (surfaces.py:14-47, 104-113, 219-243,
+502-519).  Every function mutates the ray list in place and returns None (``focus*`` return the
+total focus shift, like the reference).
+"""
+import numpy as np
+
+from . import analyses
+from . import transformations as tran
+from .native import surfacesf as surf
+from .native import woltsurf as wolt
+from .native import zernsurf as zern
+from .transformations import ind_to_mask
+
+__all__ = ["flat", "zernsurf", "conic", "wolterprimary", "wolterprimarynode", "woltersecondary", "focus",
+           "focusX", "focusY", "focusI", "zmodes"]
+
+
+def flat(rays, ind=None, nr=None):
+    """Trace rays to the XY plane (surfaces.py:14-29).  As in the reference, `ind` takes
+    precedence and the ind path does not update the OPD."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if ind is not None:
+        surf.flat(x, y, z, l, m, n, ux, uy, uz, mask=ind_to_mask(ind, x.shape[0], x.device))
+    elif nr is not None:
+        surf.flatopd(x, y, z, l, m, n, ux, uy, uz, opd, nr)
+    else:
+        surf.flat(x, y, z, l, m, n, ux, uy, uz)
+    return
+
+
+def zmodes(N):
+    """Default (rorder, aorder) for N standard Zernike terms.
+
+    The reference takes these from `utilities.imaging.zernikemod.zmodes`, a package that is not
+    vendored with PyXFocus and pinned nowhere (surfaces.py:10,36-37), so this default is PARITY
+    UNPINNED.  It is the Noll ordering that matches the comment in specialFunctions.f95:139-140
+    (Z1 = 1, Z2 = 2 r cos t; within a pair the even index is the cosine term), with the sign
+    convention zernset consumes: aorder > 0 -> cos, < 0 -> sin, 0 -> radial."""
+    ro, ao = [], []
+    n, j = 0, 1
+    while len(ro) < N:
+        for mm in range(n % 2, n + 1, 2):
+            if mm == 0:
+                ro.append(n); ao.append(0); j += 1
+            else:
+                for _ in range(2):
+                    ro.append(n); ao.append(mm if j % 2 == 0 else -mm); j += 1
+        n += 1
+    return np.array(ro[:N], dtype=np.int32), np.array(ao[:N], dtype=np.int32)
+
+
+def zernsurf(rays, coeff, rad, rorder=None, aorder=None, nr=None):
+    """Zernike sag surface about z=0; coordinates are the usual arctan2(y,x) (surfaces.py:31-47)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if rorder is None:
+        rorder, aorder = zmodes(np.size(coeff))
+    if nr is None:
+        zern.tracezern(x, y, z, l, m, n, ux, uy, uz, coeff, np.array(rorder), np.array(aorder), rad)
+    else:
+        zern.tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, np.array(rorder), np.array(aorder), rad, nr)
+    return
+
+
+def conic(rays, R, K, nr=None):
+    """Conic surface with radius of curvature R and conic constant K (surfaces.py:104-113)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if nr is not None:
+        surf.conicopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, nr)
+    else:
+        surf.conic(x, y, z, l, m, n, ux, uy, uz, R, K)
+    return
+
+
+def wolterprimary(rays, r0, z0, psi=1., nr=None):
+    """Wolter-I primary surface - no vignetting (surfaces.py:219-227)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if nr is None:
+        wolt.wolterprimary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi)
+    else:
+        wolt.wolterprimaryopd(opd, x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, nr)
+    return
+
+
+def wolterprimarynode(rays, r0, z0, psi=1.):
+    """Place Wolter node at current origin, focus at (-r0,0,-z0) (surfaces.py:229-236)."""
+    tran.transform(rays, -r0, 0, -z0, 0, 0, 0)
+    wolterprimary(rays, r0, z0, psi)
+    tran.itransform(rays, -r0, 0, -z0, 0, 0, 0)
+    return
+
+
+def woltersecondary(rays, r0, z0, psi=1.):
+    """Wolter-I secondary surface - no vignetting (surfaces.py:238-243)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    wolt.woltersecondary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi)
+    return
+
+
+def focus(rays, fn, weights=None, nr=None, coords=None):
+    """Two passes of: analytic best-focus shift -> move frame -> flat (surfaces.py:502-510)."""
+    dz1 = fn(rays, weights=weights)
+    tran.transform(rays, 0, 0, dz1, 0, 0, 0, coords=coords)
+    flat(rays, nr=nr)
+    dz2 = fn(rays, weights=weights)
+    tran.transform(rays, 0, 0, dz2, 0, 0, 0, coords=coords)
+    flat(rays, nr=nr)
+    return dz1 + dz2
+
+
+def focusY(rays, weights=None, nr=None, coords=None):
+    return focus(rays, analyses.analyticYPlane, weights=weights, nr=nr, coords=coords)
+
+
+def focusX(rays, weights=None, nr=None, coords=None):
+    return focus(rays, analyses.analyticXPlane, weights=weights, nr=nr, coords=coords)
+
+
+def focusI(rays, weights=None, nr=None, coords=None):
+    return focus(rays, analyses.analyticImagePlane, weights=weights, nr=nr, coords=coords)

@@ -1,0 +1,163 @@
+"""GPU parity tests: HIP kernels (through the C ABI) vs the oracle / the reference goldens.
+
+Bar (DESIGN.md "Parity policy"):
+  * flat, flatopd, conic, conicopd, wolterprimary[opd], woltersecondary, transform, itransform,
+    reflect: BIT-IDENTICAL to the reference (NaN == NaN).
+  * radgrat, radgratW: |err| <= 1e-14 + 1e-13|ref| on the direction cosines.
+  * tracezern[OPD]: |err| <= 2e-11 + 1e-12|ref| (positions in mm, cosines) -- well inside the
+    north-star's 1e-10 mm RMS ray-position budget.
+"""
+import numpy as np
+import pytest
+
+from oracle import cases
+from util import ALLCOLS, BITWISE, assert_cols, bits_equal, call_gpu, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _golden_cases(g):
+    for ent in g["__names__"]:
+        name, fn = str(ent).split("|")
+        cols = {k: g["%s/in/%s" % (name, k)].copy() for k in ALLCOLS}
+        args, i = [], 0
+        while "%s/arg/%d" % (name, i) in g:
+            a = g["%s/arg/%d" % (name, i)]
+            args.append(a if a.ndim else a.item())
+            i += 1
+        want = {k: g["%s/out/%s" % (name, k)] for k in cases.SIG[fn].split()}
+        yield name, fn, cols, tuple(args), want
+
+
+def test_library_loaded_on_gpu():
+    from pyxfocus_amd import _lib
+    assert torch.cuda.is_available()
+    assert _lib.lib().pxf_abi_version() == 1
+
+
+def test_golden_native_cases(golden):
+    """Every committed reference vector (N=256 per case)."""
+    for name, fn, cols, args, want in _golden_cases(golden["native_cases"]):
+        t = to_dev(cols)
+        call_gpu(fn, t, args)
+        got = to_host(t)
+        assert_cols(fn, got, want, want.keys(), context="golden:" + name)
+        # columns the function does not take must be untouched
+        for k in set(ALLCOLS) - set(cases.SIG[fn].split()):
+            assert bits_equal(got[k], cols[k]).all()
+
+
+@pytest.mark.parametrize("num", [1, 2, 63, 2049, 100003])
+def test_live_oracle_sizes(port, num):
+    """Same seeded inputs through oracle and GPU at ragged sizes (odd counts exercise the
+    vector-pair tail, 1 and 2 the degenerate grids)."""
+    for name, fn, cols, args in cases.cases(num=num, seed=4242 + num):
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, args)
+        t = to_dev(cols)
+        call_gpu(fn, t, args)
+        assert_cols(fn, to_host(t), want, ALLCOLS, context="n=%d:%s" % (num, name))
+
+
+def test_empty_bundle():
+    from pyxfocus_amd import native
+    e = [torch.empty(0, dtype=torch.float64, device="cuda") for _ in range(10)]
+    native.surfacesf.flat(*e[1:])
+    native.woltsurf.wolterprimary(*e[1:], 220., 8400., 1.)
+    native.transformationsf.transform(*e[1:], 1., 2., 3., .1, .2, .3)
+    native.transformationsf.reflect(*e[4:])
+
+
+def test_masked_equals_gather_scatter(port):
+    """`mask` (the wrappers' ind=) == gather -> oracle -> scatter; unselected rays untouched bitwise."""
+    rng = np.random.default_rng(7)
+    for name, fn, cols, args in cases.cases(num=4097, seed=31):
+        n = len(cols["x"])
+        msk = rng.random(n) < 0.37
+        want = {k: v.copy() for k, v in cols.items()}
+        sub = {k: np.ascontiguousarray(v[msk]) for k, v in cols.items()}
+        a2 = tuple(a[msk] if (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.shape == (n,)) else a
+                   for a in args)
+        cases.call(port, fn, sub, a2)
+        for k in ALLCOLS:
+            want[k][msk] = sub[k]
+        t = to_dev(cols)
+        call_gpu(fn, t, args, mask=torch.from_numpy(msk).cuda())
+        got = to_host(t)
+        assert_cols(fn, got, want, ALLCOLS, context="masked:" + name)
+        for k in ALLCOLS:
+            assert bits_equal(got[k][~msk], cols[k][~msk]).all(), "unselected rays modified: %s %s" % (name, k)
+
+
+def test_unaligned_views(port):
+    """Columns that are views at an odd element offset (8-byte aligned only) take the scalar path."""
+    for name, fn, cols, args in cases.cases(num=1500, seed=77):
+        if fn not in BITWISE:
+            continue
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, args)
+        big = {k: torch.zeros(len(v) + 3, dtype=torch.float64, device="cuda") for k, v in cols.items()}
+        t = {}
+        for k, v in cols.items():
+            t[k] = big[k][1:1 + len(v)]
+            t[k].copy_(torch.from_numpy(v))
+            assert t[k].data_ptr() % 16 == 8
+        call_gpu(fn, t, args)
+        assert_cols(fn, to_host(t), want, ALLCOLS, context="unaligned:" + name)
+        for k in big:   # guard elements around the view untouched
+            assert float(big[k][0]) == 0. and float(big[k][-1]) == 0. and float(big[k][-2]) == 0.
+
+
+def test_chain_config2_golden_and_1e6(port, golden):
+    """golden bundle bitwise, then 1e6 rays vs the oracle: RMS position error
+    (the north-star metric, target < 1e-10 mm) must be EXACTLY 0 because the chain is bit-identical."""
+    from pyxfocus_amd import native
+    g = golden["chain_config2"]
+    t = to_dev({k: g["in/" + k] for k in ALLCOLS})
+    cases.chain_config2(native, t)
+    got = to_host(t)
+    for k in ALLCOLS:
+        assert bits_equal(got[k], g["out/" + k]).all(), k
+    rng = np.random.default_rng(11)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    c = cases.annulus_rays(rng, 1_000_000, rin, rout, 0.)
+    t = to_dev(c)
+    cases.chain_config2(port, c)
+    cases.chain_config2(native, t)
+    got = to_host(t)
+    rms = np.sqrt(np.mean((got["x"] - c["x"]) ** 2 + (got["y"] - c["y"]) ** 2 + (got["z"] - c["z"]) ** 2))
+    assert rms == 0.0
+    for k in ALLCOLS:
+        assert bits_equal(got[k], c[k]).all(), k
+
+
+def test_offaxis_chain_vs_oracle(port):
+    """5 arcmin off-axis: secondary needs 3-8 Newton iterations, divergent per ray."""
+    from pyxfocus_amd import native
+    rng = np.random.default_rng(12)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    c = cases.annulus_rays(rng, 200_001, rin, rout, 0.)
+    off = 5. / 60 * np.pi / 180
+    c["l"][:] = np.sin(off)
+    c["n"][:] = -np.sqrt(1 - np.sin(off) ** 2)
+    t = to_dev(c)
+    cases.chain_config2(port, c)
+    cases.chain_config2(native, t)
+    got = to_host(t)
+    for k in ALLCOLS:
+        assert bits_equal(got[k], c[k]).all(), k
+
+
+def test_transform_roundtrip_property():
+    """Size-independent property at a larger N: itransform(transform(rays)) == rays to rounding, |d|=1."""
+    from pyxfocus_amd import native
+    n = 5_000_000
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    cols = [torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1 for _ in range(9)]
+    orig = [c.clone() for c in cols]
+    p = (1.5, -2.5, 3.5, 0.3, -0.2, 0.9)
+    native.transformationsf.transform(*cols, *p)
+    native.transformationsf.itransform(*cols, *p)
+    for a, b in zip(cols, orig):
+        assert float((a - b).abs().max()) < 5e-15

@@ -1,0 +1,326 @@
+"""GPU tests of the PyXFocus-signature layer (transformations / surfaces / analyses / sources)
+against vectors captured from the reference's OWN transformations.py + sources.py running over
+its compiled Fortran (tests/golden/wrappers.npz, sources.npz; oracle/make_golden.py)."""
+import numpy as np
+import pytest
+
+from util import ALLCOLS, bits_equal
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def rays_from(g, prefix, dev="cuda"):
+    return [torch.from_numpy(g["%s/%s" % (prefix, k)].copy()).to(dev) for k in ALLCOLS]
+
+
+def host(rays):
+    return [r.cpu().numpy() for r in rays]
+
+
+def assert_rays(got, g, prefix, exact=True, tol=0.):
+    for k, a in zip(ALLCOLS, host(got)):
+        w = g["%s/%s" % (prefix, k)]
+        assert a.shape == w.shape, "%s/%s shape %s vs %s" % (prefix, k, a.shape, w.shape)
+        if exact:
+            assert bits_equal(a, w).all(), "%s/%s" % (prefix, k)
+        else:
+            assert (np.isnan(a) == np.isnan(w)).all()
+            f = ~np.isnan(w)
+            assert np.all(np.abs(a[f] - w[f]) <= tol * (1 + np.abs(w[f]))), "%s/%s max %g" % (
+                prefix, k, np.abs(a[f] - w[f]).max())
+
+
+def test_coords_and_applyT(golden):
+    import pyxfocus_amd.transformations as tran
+    g = golden["wrappers"]
+    rays = rays_from(g, "coords/in")
+    orig = tran.copy_rays(rays)
+    coords = tran.newCoords()
+    for t in g["coords/seq"]:
+        tran.transform(rays, *t, coords=coords)
+    tran.itransform(rays, *g["coords/iseq"], coords=coords)
+    assert_rays(rays, g, "coords/out")
+    assert np.abs(np.array(coords) - g["coords/matrices"]).max() < 1e-13
+    fwd = tran.applyT(orig, coords)
+    assert fwd[0] is orig[0]                      # opd is shared, as in the reference
+    assert_rays(fwd, g, "coords/applyT_fwd", exact=False, tol=1e-13)
+    inv = tran.applyT(rays, coords, inverse=True)
+    assert_rays(inv, g, "coords/applyT_inv", exact=False, tol=1e-13)
+    # applyT(orig) == sequential transforms, and the inverse returns to the start
+    for a, b in zip(host(fwd)[1:], host(rays)[1:]):
+        assert np.abs(a - b).max() < 1e-11
+    for a, b in zip(host(inv)[1:], host(orig)[1:]):
+        assert np.abs(a - b).max() < 1e-11
+    pos = tran.applyTPos(orig[1], orig[2], orig[3], coords).cpu().numpy()
+    assert np.abs(pos - g["coords/applyTPos_fwd"]).max() < 1e-10
+    pos = tran.applyTPos(rays[1], rays[2], rays[3], coords, inverse=True).cpu().numpy()
+    assert np.abs(pos - g["coords/applyTPos_inv"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("tag", ["mask", "index", "where"])
+@pytest.mark.parametrize("as_torch", [False, True])
+def test_ind_semantics(golden, tag, as_torch):
+    import pyxfocus_amd.transformations as tran
+    g = golden["wrappers"]
+    rays = rays_from(g, "ind_%s/in" % tag)
+    ind = g["ind_%s/ind" % tag]
+    if as_torch:
+        ind = torch.from_numpy(ind).cuda()
+    if tag == "where":
+        ind = (ind,)
+    tran.transform(rays, 1., 2., 3., 0.1, 0.2, 0.3, ind=ind)
+    tran.reflect(rays, ind=ind)
+    tran.itransform(rays, -1., 0., 2., 0., 0.5, 0., ind=ind)
+    assert_rays(rays, g, "ind_%s/out" % tag)
+
+
+def test_vignette(golden):
+    import pyxfocus_amd.transformations as tran
+    g = golden["wrappers"]
+    rays = rays_from(g, "vignette/in")
+    keep = [r.clone() for r in rays]
+    assert_rays(tran.vignette(rays), g, "vignette/default")
+    assert_rays(tran.vignette(rays, ind=g["vignette/mask"]), g, "vignette/bymask")
+    assert_rays(tran.vignette(rays, ind=torch.from_numpy(g["vignette/mask"]).cuda()), g, "vignette/bymask")
+    assert_rays(tran.vignette(rays, ind=g["vignette/index"]), g, "vignette/byindex")
+    assert_rays(tran.vignette(rays, ind=np.where(g["vignette/mask"])), g, "vignette/bymask")
+    for a, b in zip(rays, keep):      # the input bundle is not modified
+        assert torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(), b.nan_to_num())
+    with pytest.raises(IndexError):
+        tran.vignette(rays, ind=np.array([len(rays[0])]))
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 2047, 2048, 2049, 1_000_003])
+def test_vignette_sizes_and_order(n):
+    """Compaction is stable and exact at tile boundaries, for empty / all / none kept."""
+    import pyxfocus_amd.transformations as tran
+    gen = np.random.default_rng(n)
+    cols = [gen.normal(size=n) for _ in range(10)]
+    for frac in (0., 0.31, 1.):
+        keep = gen.random(n) < frac if 0 < frac < 1 else np.full(n, bool(frac))
+        rays = [torch.from_numpy(c.copy()).cuda() for c in cols]
+        out = tran.vignette(rays, ind=keep)
+        for a, c in zip(out, cols):
+            assert np.array_equal(a.cpu().numpy(), c[keep])
+
+
+def test_vignette_default_predicate_large():
+    import pyxfocus_amd.transformations as tran
+    n = 3_000_001
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    rays = [torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) for _ in range(10)]
+    dead = torch.rand(n, device="cuda", generator=gen) < 0.4
+    for k in (4, 5, 6):
+        rays[k][dead] = 0.
+    rays[6][17] = float("nan")
+    out = tran.vignette(rays)
+    mag = rays[4] ** 2 + rays[5] ** 2 + rays[6] ** 2
+    ref = [r[mag > .1] for r in rays]
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tag", ["scalar", "array", "scalar_ind", "array_ind"])
+def test_radgrat_dispatch(golden, tag):
+    import pyxfocus_amd.transformations as tran
+    g = golden["wrappers"]
+    rays = rays_from(g, "radgrat_%s/in" % tag)
+    wave = g["radgrat_%s/wave" % tag]
+    wave = wave if wave.ndim else float(wave)
+    ind = g["radgrat_%s/ind" % tag] if tag.endswith("ind") else None
+    tran.radgrat(rays, 160. / 11832., 1., wave, ind=ind)
+    assert_rays(rays, g, "radgrat_%s/out" % tag, exact=False, tol=1e-13)
+
+
+def test_pointto(golden):
+    import pyxfocus_amd.transformations as tran
+    g = golden["wrappers"]
+    rays = rays_from(g, "pointto/in")
+    old_l = rays[4]
+    tran.pointTo(rays, 1., -2., 5000., reverse=1.)
+    assert rays[4] is not old_l                       # rebinding, as the reference does
+    assert_rays(rays, g, "pointto/out")
+
+
+def test_surfaces_wrappers_vs_oracle(port):
+    """surfaces.* (3-line unpack-and-call wrappers, surfaces.py) against the oracle's native calls."""
+    import pyxfocus_amd.surfaces as surf
+    from oracle import cases
+    rng = np.random.default_rng(21)
+    c = cases.primary_input(rng, 5000, offaxis=1e-3)
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    a = [c[k] for k in ALLCOLS[1:]]
+    surf.wolterprimary(rays, 220., 8400.)
+    port.woltsurf.wolterprimary(*a, 220., 8400., 1.)
+    import pyxfocus_amd.transformations as tran
+    tran.reflect(rays)
+    port.transformationsf.reflect(*a[3:])
+    surf.woltersecondary(rays, 220., 8400.)
+    port.woltsurf.woltersecondary(*a, 220., 8400., 1.)
+    tran.reflect(rays)
+    port.transformationsf.reflect(*a[3:])
+    surf.flat(rays, nr=1.)
+    port.surfacesf.flatopd(*a, c["opd"], 1.)
+    for k, r in zip(ALLCOLS, host(rays)):
+        assert bits_equal(r, c[k]).all(), k
+    # flat with ind: plain flat on the subset, OPD untouched (surfaces.py:17-24)
+    msk = rng.random(5000) < .5
+    c2 = {k: v.copy() for k, v in c.items()}
+    c2["z"] += 3.
+    rays = [torch.from_numpy(c2[k].copy()).cuda() for k in ALLCOLS]
+    sub = [np.ascontiguousarray(c2[k][msk]) for k in ALLCOLS[1:]]
+    port.surfacesf.flat(*sub)
+    surf.flat(rays, ind=msk, nr=1.)
+    for k, r, s in zip(ALLCOLS[1:], host(rays)[1:], sub):
+        assert bits_equal(r[msk], s).all() and bits_equal(r[~msk], c2[k][~msk]).all()
+    assert bits_equal(rays[0].cpu().numpy(), c2["opd"]).all()
+    # wolterprimarynode = transform -> primary -> itransform
+    c3 = cases.primary_input(rng, 1000)
+    c3["x"] += 220.; c3["z"] -= 8400.                 # node-centred frame
+    rays = [torch.from_numpy(c3[k].copy()).cuda() for k in ALLCOLS]
+    a = [c3[k] for k in ALLCOLS[1:]]
+    port.transformationsf.transform(*a, 220., 0., 8400., 0., 0., 0.)
+    port.woltsurf.wolterprimary(*a, 220., 8400., 1.)
+    port.transformationsf.itransform(*a, 220., 0., 8400., 0., 0., 0.)
+    surf.wolterprimarynode(rays, 220., 8400.)
+    for k, r in zip(ALLCOLS, host(rays)):
+        assert bits_equal(r, c3[k]).all(), k
+
+
+def test_conic_and_zernsurf_wrappers(port):
+    import pyxfocus_amd.surfaces as surf
+    from oracle import cases
+    for name, fn, cols, args in cases.cases(num=777, seed=5):
+        if fn == "surfacesf.conicopd" and name.endswith("hyper"):
+            rays = [torch.from_numpy(cols[k].copy()).cuda() for k in ALLCOLS]
+            surf.conic(rays, args[0], args[1], nr=args[2])
+            cases.call(port, fn, cols, args)
+            for k, r in zip(ALLCOLS, host(rays)):
+                assert bits_equal(r, cols[k]).all(), k
+        if name == "tracezern_36":
+            rays = [torch.from_numpy(cols[k].copy()).cuda() for k in ALLCOLS]
+            surf.zernsurf(rays, args[0], args[3], rorder=args[1], aorder=args[2])
+            cases.call(port, fn, cols, args)
+            for k, r in zip(ALLCOLS, host(rays)):
+                f = ~np.isnan(cols[k])
+                assert (np.isnan(r) == np.isnan(cols[k])).all()
+                assert np.abs(r[f] - cols[k][f]).max() < 2e-11, k
+            # default ordering == the Noll ordering the test cases use
+            ro, ao = surf.zmodes(36)
+            assert np.array_equal(ro, args[1]) and np.array_equal(ao, args[2])
+
+
+def test_analyses_vs_numpy(golden):
+    """analyses.* reductions (restated from analyses.py text; np.average formulas) on the golden
+    focal-plane bundle and on weighted random data."""
+    import pyxfocus_amd.analyses as anal
+    g = golden["chain_config2"]
+    rays = [torch.from_numpy(g["out/" + k].copy()).cuda() for k in ALLCOLS]
+    x, y = g["out/x"], g["out/y"]
+    assert abs(anal.rmsCentroid(rays) - float(g["rms_centroid"])) < 1e-18 + 1e-9 * float(g["rms_centroid"])
+    cx, cy = anal.centroid(rays)
+    assert abs(cx - np.average(x)) < 1e-15 and abs(cy - np.average(y)) < 1e-15
+    r = np.sqrt((x - np.average(x)) ** 2 + (y - np.average(y)) ** 2)
+    assert abs(anal.hpd(rays) - 2 * np.median(r)) < 1e-18
+    rng = np.random.default_rng(9)
+    n = 100_001
+    c = {k: rng.normal(size=n) for k in ALLCOLS}
+    c["n"] = -np.abs(c["n"]) - .5
+    w = rng.random(n)
+    rays = [torch.from_numpy(c[k]).cuda() for k in ALLCOLS]
+    for wt in (None, w):
+        x, y, l, m, nn = c["x"], c["y"], c["l"], c["m"], c["n"]
+        av = lambda a: np.average(a, weights=wt)
+        bx = av(x * l / nn) - av(x) * av(l / nn); ax = av((l / nn) ** 2) - av(l / nn) ** 2
+        by = av(y * m / nn) - av(y) * av(m / nn); ay = av((m / nn) ** 2) - av(m / nn) ** 2
+        assert abs(anal.analyticImagePlane(rays, weights=wt) - (-(bx + by) / (ax + ay))) < 1e-11
+        assert abs(anal.analyticXPlane(rays, weights=wt) - (-bx / ax)) < 1e-11
+        assert abs(anal.analyticYPlane(rays, weights=wt) - (-by / ay)) < 1e-11
+        cx, cy = av(x), av(y)
+        assert abs(anal.rmsCentroid(rays, weights=wt) - np.sqrt(av((x - cx) ** 2 + (y - cy) ** 2))) < 1e-12
+        assert abs(anal.rmsX(rays, weights=wt) - np.sqrt(av((x - cx) ** 2))) < 1e-12
+        assert abs(anal.rmsY(rays, weights=wt) - np.sqrt(av((y - cy) ** 2))) < 1e-12
+    # weighted hpd (argsort + cdf, analyses.py:73-97)
+    rr = np.sqrt((c["x"] - np.average(c["x"], weights=w)) ** 2 + (c["y"] - np.average(c["y"], weights=w)) ** 2)
+    ind = np.argsort(rr); cdf = np.cumsum(w[ind]); cdf /= cdf.max(); rs = rr[ind]
+    want = rs[np.argmin(np.abs(cdf - .75))] - rs[np.argmin(np.abs(cdf - .25))]
+    assert abs(anal.hpd(rays, weights=w) - want) < 1e-12
+
+
+def test_focusI_and_steer():
+    """focusI brings an on-axis Wolter pair to best focus; steerX/Y zero the mean tilt."""
+    import pyxfocus_amd.analyses as anal
+    import pyxfocus_amd.sources as sources
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from pyxfocus_amd import conicsolve as con
+    r0, z0 = 220., 8400.
+    rays = sources.annulus(con.primrad(z0, r0, z0), con.primrad(z0 + 100., r0, z0), 200_000,
+                           rng="philox", seed=5)
+    tran.transform(rays, 0, 0, -(z0 + 200.), 0, 0, 0)
+    surf.wolterprimary(rays, r0, z0)
+    tran.reflect(rays)
+    surf.woltersecondary(rays, r0, z0)
+    tran.reflect(rays)
+    tran.transform(rays, 0, 0, 25., 0, 0, 0)         # deliberately 25 mm off focus
+    surf.flat(rays)
+    blur = anal.rmsCentroid(rays)
+    coords = tran.newCoords()
+    dz = surf.focusI(rays, coords=coords)
+    assert abs(dz + 25.) < 1e-3 and anal.rmsCentroid(rays) < 1e-4 < blur
+    assert abs(coords[1][2, 3] + dz) < 1e-9
+    tran.transform(rays, 0, 0, 0, 1e-3, -2e-3, 0)
+    tran.steerX(rays); tran.steerY(rays)
+    assert abs(float(rays[4].mean())) < 1e-6 and abs(float(rays[5].mean())) < 1e-6
+
+
+def test_sources_numpy_path_on_device(golden):
+    import pyxfocus_amd.sources as sources
+    g = golden["sources"]
+    np.random.seed(int(g["subannulus/seed"]))
+    a = g["subannulus/args"]
+    rays = sources.subannulus(a[0], a[1], a[2], int(a[3]))
+    assert rays[1].is_cuda
+    for k, r in zip(ALLCOLS, host(rays)):
+        assert bits_equal(r, g["subannulus/" + k]).all()
+
+
+def test_sources_philox_distribution_and_sharding():
+    """Device RNG: same distribution as the reference formulas; a bundle generated in two shards
+    (first_index offset) is bit-identical to the single bundle."""
+    import pyxfocus_amd.sources as sources
+    n = 2_000_000
+    rin, rout = 220., 220.6537
+    rays = sources.annulus(rin, rout, n, rng="philox", seed=42)
+    x, y = rays[1], rays[2]
+    r2 = x * x + y * y
+    assert float(r2.min()) >= rin ** 2 * (1 - 1e-15) and float(r2.max()) <= rout ** 2 * (1 + 1e-15)
+    u = ((r2 - rin ** 2) / (rout ** 2 - rin ** 2)).cpu().numpy()      # uniform in area
+    assert abs(u.mean() - .5) < 2e-3 and abs(u.var() - 1 / 12.) < 2e-3
+    th = torch.atan2(y, x).cpu().numpy()
+    assert abs(th.mean()) < 5e-3 and abs(np.mean(np.cos(2 * th))) < 3e-3
+    assert torch.all(rays[6] == -1.) and torch.all(rays[3] == 0.) and torch.all(rays[0] == 0.)
+    a = sources.annulus(rin, rout, n // 2, rng="philox", seed=42, first_index=0)
+    b = sources.annulus(rin, rout, n - n // 2, rng="philox", seed=42, first_index=n // 2)
+    for full, p, q in zip(rays, a, b):
+        assert torch.equal(full, torch.cat([p, q]))
+    ps = sources.pointsource(0.01, 100_001, rng="philox", seed=1)
+    mag = ps[4] ** 2 + ps[5] ** 2 + ps[6] ** 2
+    assert float((mag - 1).abs().max()) < 4e-16
+    assert float((ps[4] ** 2 + ps[5] ** 2).max()) <= np.sin(0.01) ** 2 * (1 + 1e-12)
+    sa = sources.subannulus(100., 110., 0.5, 100_000, rng="philox", seed=2)
+    ang = torch.atan2(sa[2], sa[1])
+    assert float(ang.abs().max()) <= 0.25 + 1e-12 and torch.all(sa[6] == 1.)
+    rb = sources.rectbeam(3., 4., 100_000, rng="philox", seed=3)
+    assert float(rb[1].abs().max()) <= 3. and float(rb[2].abs().max()) <= 4.
+    cb = sources.circularbeam(50., 100_000, rng="philox", seed=4)
+    assert float((cb[1] ** 2 + cb[2] ** 2).max()) <= 2500. * (1 + 1e-12)
+
+
+def test_cpu_tensors_rejected_loudly():
+    import pyxfocus_amd.sources as sources
+    import pyxfocus_amd.surfaces as surf
+    rays = sources.circularbeam(1., 8, device="cpu")
+    with pytest.raises(TypeError):
+        surf.flat(rays)

@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+ALLCOLS = "opd x y z l m n ux uy uz".split()
+
+# functions whose HIP kernels are bit-identical to the reference (add/mul/div/sqrt only, no FMA)
+BITWISE = {"surfacesf.flat", "surfacesf.flatopd", "surfacesf.conic", "surfacesf.conicopd",
+           "woltsurf.wolterprimary", "woltsurf.wolterprimaryopd", "woltsurf.woltersecondary",
+           "transformationsf.transform", "transformationsf.itransform", "transformationsf.reflect"}
+# tolerance-parity functions: |gpu - ref| <= atol + rtol*|ref| per column (stated in DESIGN.md)
+TOL = {"transformationsf.radgrat": (1e-14, 1e-13), "transformationsf.radgratw": (1e-14, 1e-13),
+       "zernsurf.tracezern": (2e-11, 1e-12), "zernsurf.tracezernopd": (2e-11, 1e-12)}
+
+
+def bits_equal(a, b):
+    """Bitwise equality of float64 arrays, NaN == NaN (any payload), -0 != +0 NOT enforced."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return (a == b) | (np.isnan(a) & np.isnan(b))
+
+
+def assert_cols(fn, got, want, cols, context=""):
+    for k in cols:
+        g, w = got[k], want[k]
+        if fn in BITWISE:
+            ok = bits_equal(g, w)
+            assert ok.all(), "%s %s col %s: %d of %d rays differ (max |d| = %g)" % (
+                context, fn, k, int((~ok).sum()), len(w), float(np.nanmax(np.abs(g - w))))
+        else:
+            atol, rtol = TOL[fn]
+            nan_same = np.isnan(g) == np.isnan(w)
+            assert nan_same.all(), "%s %s col %s: NaN pattern differs on %d rays" % (
+                context, fn, k, int((~nan_same).sum()))
+            f = ~np.isnan(w)
+            err = np.abs(g[f] - w[f])
+            lim = atol + rtol * np.abs(w[f])
+            assert (err <= lim).all(), "%s %s col %s: max err %g (limit %g)" % (
+                context, fn, k, float(err.max()), float(lim[np.argmax(err - lim)]))
+
+
+def to_dev(cols, device="cuda"):
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in cols.items()}
+
+
+def to_host(tcols):
+    return {k: v.detach().cpu().numpy() for k, v in tcols.items()}
+
+
+def call_gpu(fn_path, tcols, args, mask=None):
+    """Run one oracle/cases.py case through pyxfocus_amd.native on device tensors."""
+    from oracle import cases
+    from pyxfocus_amd import native
+    mod, fn = fn_path.split(".")
+    f = getattr(getattr(native, mod), fn)
+    arrs = [tcols[k] for k in cases.SIG[fn_path].split()]
+    import torch
+    a2 = []
+    for a in args:
+        if fn_path == "transformationsf.radgratw" and isinstance(a, np.ndarray) and a.ndim == 1 and \
+                a.dtype == np.float64 and len(a) == len(arrs[0]):
+            a = torch.from_numpy(a).to(arrs[0].device)
+        a2.append(a)
+    f(*arrs, *a2, mask=mask)
