@@ -219,8 +219,9 @@ size_t pxf_compact_workspace_bytes(int64_t num)
 int pxf_vignette_mask(const double *l, const double *m, const double *n, int64_t num, uint8_t *mask_out,
                       pxf_stream_t stream)
 {
-    if (num < 0 || !l || !m || !n || !mask_out) return PXF_EINVAL;
+    if (num < 0) return PXF_EINVAL;
     if (num == 0) return PXF_OK;
+    if (!l || !m || !n || !mask_out) return PXF_EINVAL;
     const int vec2 = ((((uintptr_t)l | (uintptr_t)m | (uintptr_t)n) & 15) == 0) && (((uintptr_t)mask_out & 1) == 0);
     hipLaunchKernelGGL(vignette_mask_kernel, dim3(grid_for(vec2 ? (num + 1) / 2 : num)), dim3(kBlock), 0,
                        (hipStream_t)stream, l, m, n, num, mask_out, vec2);
@@ -245,11 +246,11 @@ int pxf_compact_scan(const uint8_t *mask, int64_t num, void *workspace, int64_t 
 int pxf_compact_scatter(const double *const *in_cols, double *const *out_cols, int32_t ncols, int64_t num,
                         const uint8_t *mask, const void *workspace, pxf_stream_t stream)
 {
+    if (num == 0) return PXF_OK;
     ColPtrs p{};
     int rc = fill_ptrs(p, in_cols, out_cols, ncols);
     if (rc != PXF_OK) return rc;
-    if (num < 0 || !workspace || (num > 0 && !mask)) return PXF_EINVAL;
-    if (num == 0) return PXF_OK;
+    if (num < 0 || !workspace || !mask) return PXF_EINVAL;
     const int64_t nt = ntiles_for(num);
     if (nt > 0x7fffffffLL) return PXF_ERANGE;
     hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nt), dim3(kBlock), 0, (hipStream_t)stream, p,
@@ -261,11 +262,11 @@ int pxf_compact_scatter(const double *const *in_cols, double *const *out_cols, i
 int pxf_gather(const double *const *in_cols, double *const *out_cols, int32_t ncols, const int64_t *index,
                int64_t nidx, int64_t num, pxf_stream_t stream)
 {
+    if (nidx == 0) return PXF_OK;
     ColPtrs p{};
     int rc = fill_ptrs(p, in_cols, out_cols, ncols);
     if (rc != PXF_OK) return rc;
-    if (nidx < 0 || num < 0 || (nidx > 0 && !index)) return PXF_EINVAL;
-    if (nidx == 0) return PXF_OK;
+    if (nidx < 0 || num < 0 || !index) return PXF_EINVAL;
     hipLaunchKernelGGL(gather_kernel, dim3(grid_for(nidx)), dim3(kBlock), 0, (hipStream_t)stream, p, (int)ncols,
                        index, nidx, num, (int *)nullptr);
     hipError_t e = hipGetLastError();

@@ -159,6 +159,7 @@ template <class Op>
 int launch_rays(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream, const Op &op)
 {
     if (num < 0) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;  // an empty bundle is a no-op (its columns may be NULL)
     bool aligned = true;
     for (int col = 0; col < NCOL; col++) {
         if ((Op::RD | Op::WR) & B(col)) {
@@ -166,7 +167,6 @@ int launch_rays(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t st
             if ((uintptr_t)c.p[col] & 15) aligned = false;
         }
     }
-    if (num == 0) return PXF_OK;
     hipStream_t s = (hipStream_t)stream;
     int64_t nvec2 = 0;
     if constexpr (Op::MAXV >= 2) {

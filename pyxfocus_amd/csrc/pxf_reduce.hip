@@ -159,7 +159,7 @@ size_t pxf_reduce_workspace_bytes(void) { return (size_t)kRedMaxBlocks * PXF_NMO
 int pxf_moments(const double *x, const double *y, const double *l, const double *m, const double *n,
                 const double *w, int64_t num, double *out_dev, void *workspace, pxf_stream_t stream)
 {
-    if (num < 0 || !x || !y || !out_dev || !workspace) return PXF_EINVAL;
+    if (num < 0 || !out_dev || !workspace || (num > 0 && (!x || !y))) return PXF_EINVAL;
     const bool hasdir = l && m && n;
     if (!hasdir && (l || m || n)) return PXF_EINVAL;
     if (device_cus() * kMaxBlocksPerCU > kRedMaxBlocks) return PXF_ERANGE;
@@ -189,7 +189,7 @@ int pxf_moments(const double *x, const double *y, const double *l, const double 
 int pxf_central_moments(const double *x, const double *y, const double *w, int64_t num, double cx, double cy,
                         double *out_dev, void *workspace, pxf_stream_t stream)
 {
-    if (num < 0 || !x || !y || !out_dev || !workspace) return PXF_EINVAL;
+    if (num < 0 || !out_dev || !workspace || (num > 0 && (!x || !y))) return PXF_EINVAL;
     if (device_cus() * kMaxBlocksPerCU > kRedMaxBlocks) return PXF_ERANGE;
     const uintptr_t al = (uintptr_t)x | (uintptr_t)y | (uintptr_t)w;
     hipStream_t s = (hipStream_t)stream;

@@ -130,6 +130,7 @@ extern "C" int pxf_source(int32_t kind, double *const *cols, int64_t num, double
                           double p3, uint64_t seed, uint64_t first_index, pxf_stream_t stream)
 {
     if (num < 0 || !cols) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
     Cols c{};
     bool aligned = true;
     for (int k = 0; k < 10; k++) {

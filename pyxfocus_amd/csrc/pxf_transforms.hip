@@ -193,6 +193,7 @@ static int launch_applyt(const Cols &in, const Cols &out, int ngroups, int64_t n
                          const double *mdir, pxf_stream_t stream)
 {
     if (num < 0 || !mpos || (ngroups == 3 && !mdir)) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
     bool aligned = true;
     for (int g = 0; g < 3 * ngroups; g++) {
         if (!in.p[X + g] || !out.p[X + g]) return PXF_EINVAL;

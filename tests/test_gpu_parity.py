@@ -48,7 +48,7 @@ def test_golden_native_cases(golden):
             assert bits_equal(got[k], cols[k]).all()
 
 
-@pytest.mark.parametrize("num", [1, 2, 63, 2049, 100003])
+@pytest.mark.parametrize("num", [5, 6, 63, 2049, 100003])
 def test_live_oracle_sizes(port, num):
     """Same seeded inputs through oracle and GPU at ragged sizes (odd counts exercise the
     vector-pair tail, 1 and 2 the degenerate grids)."""
@@ -58,6 +58,24 @@ def test_live_oracle_sizes(port, num):
         t = to_dev(cols)
         call_gpu(fn, t, args)
         assert_cols(fn, to_host(t), want, ALLCOLS, context="n=%d:%s" % (num, name))
+
+
+@pytest.mark.parametrize("num", [1, 2, 3])
+def test_degenerate_sizes(port, num):
+    from pyxfocus_amd import native
+    rng = np.random.default_rng(num)
+    c = cases._randrays(rng, num)
+    t = to_dev(c)
+    a = [c[k] for k in ALLCOLS[1:]]
+    d = [t[k] for k in ALLCOLS[1:]]
+    for be, cols in ((port, a), (native, d)):
+        be.transformationsf.transform(*cols, 1., 2., 3., .1, .2, .3)
+        be.surfacesf.flat(*cols)
+        be.transformationsf.reflect(*cols[3:])
+        be.surfacesf.conic(*cols, 1000., -1.)
+    got = to_host(t)
+    for k in ALLCOLS:
+        assert bits_equal(got[k], c[k]).all(), k
 
 
 def test_empty_bundle():
