@@ -62,6 +62,17 @@ def cpu_baseline(target_seconds=12.0):
     """Reference Fortran (oracle/_ref, OpenMP build) -- or our C port if _ref did not travel --
     timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import api, cases
+    # threads actually usable: the cgroup CPU quota (16 on a 1-GPU box), not the 256 visible cores;
+    # must be in the environment BEFORE the OpenMP runtime initialises
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or cores
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     kind, be = "port", None
     try:
         if api.ref_available(omp=True):
@@ -70,8 +81,6 @@ def cpu_baseline(target_seconds=12.0):
         be = None
     if be is None:
         be = api.load_port(omp=True)
-    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     n = 4_000_000
     rng = np.random.default_rng(0)
     rin, rout = cases.primrad(Z0), cases.primrad(Z0 + LMIR)

@@ -43,7 +43,8 @@ def all_gather_focal(cols, group=None):
     for i, c in enumerate(cols):
         send[i, :n] = c
     recv = torch.empty((world, len(cols), maxlen), dtype=dt, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    # flat views: RCCL and gloo both accept (world*k,) <- (k,)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     return [torch.cat([recv[r, i, :counts[r]] for r in range(world)]) for i in range(len(cols))]
 
 

@@ -1,0 +1,88 @@
+"""Multi-process tests on CPU (gloo, world_size 2): the ray-sharding and focal-plane exchange
+logic of pyxfocus_amd/dist.py.  The per-shard trace is done by the ORACLE here (there is no CPU
+product path); what is under test is the N>1 plumbing: contiguous global-index shards, the
+uneven all-gather, and all-reduced moments giving the global metric."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import cases
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import api
+        from pyxfocus_amd import dist as pdist
+        be = api.load_port()
+        rng = np.random.default_rng(123)                    # identical global bundle on every rank
+        rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+        full = cases.annulus_rays(rng, n, rin, rout, 0.)
+        lo, hi = pdist.shard_range(n)
+        mine = {k: np.ascontiguousarray(v[lo:hi]) for k, v in full.items()}
+        cases.chain_config2(be, mine)
+        # vignette-like uneven survivors: keep rays with x > 0 (different count per rank)
+        keep = mine["x"] > -1e-4
+        cols = [torch.from_numpy(mine[k][keep]) for k in ("x", "y")]
+        gx, gy = pdist.all_gather_focal(cols)
+        # moments: [S1, Sx, Sy] all-reduced -> global centroid
+        s = torch.tensor([len(mine["x"]), mine["x"].sum(), mine["y"].sum()], dtype=torch.float64)
+        pdist.all_reduce_sums(s)
+        q.put((rank, lo, hi, gx.numpy(), gy.numpy(), s.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [10001, 4096])
+def test_sharded_trace_equals_single_process(n):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process truth
+    from oracle import api
+    be = api.load_port()
+    rng = np.random.default_rng(123)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    full = cases.annulus_rays(rng, n, rin, rout, 0.)
+    cases.chain_config2(be, full)
+    keep = full["x"] > -1e-4
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n           # shards tile [0, n)
+    assert abs((res[0][2] - res[0][1]) - (res[1][2] - res[1][1])) <= 1
+    for rank, lo, hi, gx, gy, s in res:
+        assert np.array_equal(gx, full["x"][keep]) and np.array_equal(gy, full["y"][keep])   # global ray order
+        assert s[0] == n
+        assert abs(s[1] / s[0] - full["x"].mean()) < 1e-12 and abs(s[2] / s[0] - full["y"].mean()) < 1e-12
+
+
+def test_shard_range_properties():
+    from pyxfocus_amd.dist import shard_range
+    for total in (0, 1, 7, 8, 1000003, 8 * 10 ** 9):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            for a, b in zip(edges, edges[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
