@@ -81,14 +81,14 @@ def cpu_baseline(target_seconds=12.0):
         be = None
     if be is None:
         be = api.load_port(omp=True)
-    n = 4_000_000
+    n = 10_000_000
     rng = np.random.default_rng(0)
     rin, rout = cases.primrad(Z0), cases.primrad(Z0 + LMIR)
     src = cases.annulus_rays(rng, n, rin, rout, 0.)
     c = {k: v.copy() for k, v in src.items()}
     cases.chain_config2(be, c)                      # warm-up (page faults, thread pool)
     reps, spent = 0, 0.0
-    while spent < target_seconds and reps < 200:
+    while spent < target_seconds and reps < 5000:
         c = {k: v.copy() for k, v in src.items()}
         t0 = time.perf_counter()
         cases.chain_config2(be, c)
@@ -109,17 +109,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--pool-gb", type=float, default=200.0, help="HBM budget for pre-generated bundles")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "rehearse the N>1 path with several ranks sharing one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(1, torch.cuda.device_count())   # (rehearsal: ranks may share a GPU under gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
     n_gpus = world
 
     import pyxfocus_amd.analyses as anal

@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  -- must load first: libpxf_hip.so binds to the HIP runtime torch loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpxf_hip.so")
+# PXF_LIB: development override (A/B of build variants); the product path is the in-tree library
+LIB_PATH = os.environ.get("PXF_LIB") or os.path.join(_HERE, "csrc", "libpxf_hip.so")
 
 PXF_NMOM = 12
 SRC_KINDS = {"pointsource": 0, "circularbeam": 1, "annulus": 2, "subannulus": 3, "rectbeam": 4}

@@ -1,4 +1,6 @@
 // pxf_core.hip -- ABI version, error strings, per-thread HIP error slot, device query.
+#include <stdlib.h>
+
 #include "pxf_kernel.h"
 
 namespace pxf {
@@ -19,6 +21,28 @@ int device_cus()
             cus = 256;  // MI355X
     }
     return cus;
+}
+
+int blocks_per_cu_cap()
+{
+    static int bpc = -1;
+    if (bpc < 0) {
+        const char *e = getenv("PXF_BPC");
+        bpc = e ? atoi(e) : kDefaultBlocksPerCU;
+        if (bpc < 0) bpc = 0;
+    }
+    return bpc;
+}
+
+bool use_nt(int64_t num)
+{
+    static int64_t min_rays = -1;
+    if (min_rays < 0) {
+        const char *e = getenv("PXF_NT_MIN_RAYS");
+        // default: the ten-column bundle (80 B/ray) no longer fits the 256 MiB Infinity Cache
+        min_rays = e ? atoll(e) : (256LL << 20) / 80;
+    }
+    return num >= min_rays;
 }
 
 }  // namespace pxf

@@ -6,8 +6,9 @@
 //    = 1 KiB per wave-instruction, the widest coalesced access the hardware has.  V=1 is the
 //    fallback for columns that are only 8-byte aligned (views into a larger tensor).
 //  * All loads of an iteration are issued back-to-back before any arithmetic (6-10 independent
-//    16-B loads in flight per lane), stores at the end; the grid is capped at 8 blocks per CU
-//    and grid-strides the rest.
+//    16-B loads in flight per lane), stores at the end.  The grid is UNCAPPED (one workgroup per
+//    512 rays) and accesses are non-temporal once the bundle outgrows the 256 MiB Infinity Cache:
+//    both measured (tools/ab_kernels.py), together +10 % over "8 workgroups/CU + grid-stride".
 //  * An Op declares at compile time which columns it READS and which it WRITES; nothing else is
 //    touched, which is what makes the HBM traffic equal the algorithmic byte count.
 //  * `apply` returns the set of columns to store for that ray (conic must leave position and
@@ -21,6 +22,11 @@
 
 #include "../../include/pxf.h"
 
+// build-time tunable (A/B'd with tools/ab_kernels.py)
+#ifndef PXF_BLOCK
+#define PXF_BLOCK 256
+#endif
+
 namespace pxf {
 
 enum Col : int { OPD = 0, X, Y, Z, L, M, N, UX, UY, UZ, AUX, NCOL };
@@ -33,8 +39,11 @@ struct Cols {
     double *p[NCOL];
 };
 
-constexpr int kBlock = 256;
-constexpr int kMaxBlocksPerCU = 8;
+constexpr int kBlock = PXF_BLOCK;
+constexpr int kMaxBlocksPerCU = 8;      // reductions: partial rows per CU
+// streaming kernels: grid cap per CU; 0 = uncapped, one workgroup per 512 rays (measured +6 % over
+// the usual "8 per CU + grid-stride": in-order dispatch keeps all CUs on neighbouring DRAM pages)
+constexpr int kDefaultBlocksPerCU = 0;
 constexpr int kNewtonCap = 1000;  // the reference has none (it would hang); never reached on
                                   // inputs the reference terminates on
 
@@ -53,26 +62,45 @@ struct VecT<2> {
     using type = double2;
 };
 
-template <int V>
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// NT = non-temporal access.  Measured on MI355X (tools/ab_kernels.py, interleaved rounds): for a
+// bundle that does not fit the 256 MiB Infinity Cache, nt loads + nt stores are worth +4 % over
+// plain accesses (6.2 vs 5.9 TB/s); for a bundle that DOES fit, plain accesses keep the columns
+// on die between the launches of a chain and win by 20 % (6.6 vs 5.5 TB/s at 3e6 rays).  So NT is
+// a runtime choice per launch (use_nt() below), compiled as a template parameter.
+template <int V, bool NT = false>
 __device__ __forceinline__ void load_col(const double *p, int64_t v, double (&r)[V])
 {
     if constexpr (V == 1) {
-        r[0] = p[v];
+        r[0] = NT ? __builtin_nontemporal_load(p + v) : p[v];
     } else {
-        const double2 t = *reinterpret_cast<const double2 *>(p + 2 * v);
+        const d2_t *q = reinterpret_cast<const d2_t *>(p + 2 * v);
+        const d2_t t = NT ? __builtin_nontemporal_load(q) : *q;
         r[0] = t.x;
         r[1] = t.y;
     }
 }
 
-template <int V>
+template <int V, bool NT = false>
 __device__ __forceinline__ void store_col(double *p, int64_t v, const double (&r)[V], const bool (&w)[V])
 {
     if constexpr (V == 1) {
-        if (w[0]) p[v] = r[0];
+        if (w[0]) {
+            if (NT)
+                __builtin_nontemporal_store(r[0], p + v);
+            else
+                p[v] = r[0];
+        }
     } else {
         if (w[0] && w[1]) {
-            *reinterpret_cast<double2 *>(p + 2 * v) = make_double2(r[0], r[1]);
+            d2_t t;
+            t.x = r[0];
+            t.y = r[1];
+            if (NT)
+                __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(p + 2 * v));
+            else
+                *reinterpret_cast<d2_t *>(p + 2 * v) = t;
         } else {
             if (w[0]) p[2 * v] = r[0];
             if (w[1]) p[2 * v + 1] = r[1];
@@ -96,7 +124,7 @@ struct Ray {
 //   static constexpr unsigned RD, WR;            column bitmasks
 //   template<int V> __device__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const;
 // `sel[v]` says whether ray v takes part (mask / tail), `wm[v]` receives the columns to store.
-template <class Op, int V, bool MASKED>
+template <class Op, int V, bool MASKED, bool NT>
 __global__ __launch_bounds__(kBlock) void ray_kernel(Cols c, int64_t first, int64_t nvec,
                                                      const uint8_t *__restrict__ mask, Op op)
 {
@@ -111,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void ray_kernel(Cols c, int64_t first, int6
         for (int col = 0; col < NCOL; col++) {
             if (Op::RD & B(col)) {
                 double t[V];
-                load_col<V>(c.p[col], vv, t);
+                load_col<V, NT>(c.p[col], vv, t);
 #pragma unroll
                 for (int k = 0; k < V; k++) r[k].c[col] = t[k];
             }
@@ -132,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void ray_kernel(Cols c, int64_t first, int6
                     t[k] = r[k].c[col];
                     w[k] = sel[k] && (wm[k] & B(col));
                 }
-                store_col<V>(c.p[col], vv, t, w);
+                store_col<V, NT>(c.p[col], vv, t, w);
             }
         }
     }
@@ -141,6 +169,8 @@ __global__ __launch_bounds__(kBlock) void ray_kernel(Cols c, int64_t first, int6
 // ---- host side ---------------------------------------------------------------------------
 extern thread_local int g_last_hip_error;
 int device_cus();
+int blocks_per_cu_cap();
+bool use_nt(int64_t num);  // bundle (80 B/ray) larger than the Infinity Cache -> non-temporal accesses  // 0 = no cap: one workgroup per 256 ray-vectors (env PXF_BPC overrides)
 
 inline int hip_fail(hipError_t e)
 {
@@ -149,6 +179,14 @@ inline int hip_fail(hipError_t e)
 }
 
 inline int grid_for(int64_t nvec)
+{
+    int64_t want = (nvec + kBlock - 1) / kBlock;
+    const int bpc = blocks_per_cu_cap();
+    int64_t cap = bpc > 0 ? (int64_t)device_cus() * bpc : 0x7fffffffLL;
+    return (int)(want < cap ? want : cap);
+}
+
+inline int grid_capped(int64_t nvec)  // reductions: one partial row per workgroup, bounded workspace
 {
     int64_t want = (nvec + kBlock - 1) / kBlock;
     int64_t cap = (int64_t)device_cus() * kMaxBlocksPerCU;
@@ -168,27 +206,32 @@ int launch_rays(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t st
         }
     }
     hipStream_t s = (hipStream_t)stream;
+    const bool nt = use_nt(num);
     int64_t nvec2 = 0;
+#define PXF_LAUNCH(V, M, T, FIRST, NVEC)                                                             \
+    hipLaunchKernelGGL((ray_kernel<Op, V, M, T>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, \
+                       NVEC, mask, op)
+#define PXF_LAUNCH_V(V, FIRST, NVEC)                 \
+    do {                                             \
+        if (mask) {                                  \
+            if (nt) PXF_LAUNCH(V, true, true, FIRST, NVEC);   \
+            else PXF_LAUNCH(V, true, false, FIRST, NVEC);     \
+        } else {                                     \
+            if (nt) PXF_LAUNCH(V, false, true, FIRST, NVEC);  \
+            else PXF_LAUNCH(V, false, false, FIRST, NVEC);    \
+        }                                            \
+    } while (0)
     if constexpr (Op::MAXV >= 2) {
         nvec2 = aligned ? num / 2 : 0;
-        if (nvec2 == 0) {
-        } else if (mask)
-            hipLaunchKernelGGL((ray_kernel<Op, 2, true>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c,
-                               (int64_t)0, nvec2, mask, op);
-        else
-            hipLaunchKernelGGL((ray_kernel<Op, 2, false>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c,
-                               (int64_t)0, nvec2, mask, op);
+        if (nvec2 > 0) PXF_LAUNCH_V(2, (int64_t)0, nvec2);
     }
     const int64_t done = nvec2 * 2;
     if (done < num) {  // unaligned columns, or the odd last ray
         const int64_t rest = num - done;
-        if (mask)
-            hipLaunchKernelGGL((ray_kernel<Op, 1, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done,
-                               rest, mask, op);
-        else
-            hipLaunchKernelGGL((ray_kernel<Op, 1, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done,
-                               rest, mask, op);
+        PXF_LAUNCH_V(1, done, rest);
     }
+#undef PXF_LAUNCH_V
+#undef PXF_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }

@@ -132,7 +132,7 @@ static int run_reduce(int64_t num, bool aligned, double *out_dev, void *workspac
     const int64_t nvec2 = aligned ? num / 2 : 0;
     bool wrote = false;
     if (nvec2 > 0) {
-        const int g = grid_for(nvec2);
+        const int g = grid_capped(nvec2);
         launch(2, g, (int64_t)0, nvec2, partial);
         hipLaunchKernelGGL((fold_rows_kernel<K>), dim3(1), dim3(kBlock), 0, s, partial, g, out_dev, 0);
         wrote = true;
@@ -140,7 +140,7 @@ static int run_reduce(int64_t num, bool aligned, double *out_dev, void *workspac
     const int64_t done = nvec2 * 2;
     if (done < num || !wrote) {
         const int64_t rest = num - done;
-        const int g = rest > 0 ? grid_for(rest) : 0;
+        const int g = rest > 0 ? grid_capped(rest) : 0;
         if (g > 0) launch(1, g, done, rest, partial);
         hipLaunchKernelGGL((fold_rows_kernel<K>), dim3(1), dim3(kBlock), 0, s, partial, g, out_dev, wrote ? 1 : 0);
     }

@@ -86,7 +86,7 @@ __device__ __forceinline__ void make_ray(const SrcParams &q, uint64_t gidx, doub
     }
 }
 
-template <int KIND, int V>
+template <int KIND, int V, bool NT>
 __global__ __launch_bounds__(kBlock) void source_kernel(Cols cols, int64_t first, int64_t nvec, SrcParams q)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void source_kernel(Cols cols, int64_t first
                 t[k] = r[k][col];
                 w[k] = true;
             }
-            store_col<V>(cols.p[col], vv, t, w);
+            store_col<V, NT>(cols.p[col], vv, t, w);
         }
     }
 }
@@ -113,13 +113,19 @@ template <int KIND>
 static void launch_kind(const Cols &c, bool aligned, int64_t num, const SrcParams &q, hipStream_t s)
 {
     const int64_t nvec2 = aligned ? num / 2 : 0;
-    if (nvec2 > 0)
-        hipLaunchKernelGGL((source_kernel<KIND, 2>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0,
-                           nvec2, q);
+    const bool nt = use_nt(num);
+    if (nvec2 > 0) {
+        if (nt)
+            hipLaunchKernelGGL((source_kernel<KIND, 2, true>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c,
+                               (int64_t)0, nvec2, q);
+        else
+            hipLaunchKernelGGL((source_kernel<KIND, 2, false>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c,
+                               (int64_t)0, nvec2, q);
+    }
     const int64_t done = nvec2 * 2;
     if (done < num)
-        hipLaunchKernelGGL((source_kernel<KIND, 1>), dim3(grid_for(num - done)), dim3(kBlock), 0, s, c, done,
-                           num - done, q);
+        hipLaunchKernelGGL((source_kernel<KIND, 1, false>), dim3(grid_for(num - done)), dim3(kBlock), 0, s, c,
+                           done, num - done, q);
 }
 
 }  // namespace pxf
