@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--rays", type=float, default=1e8, help="rays per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--pool-gb", type=float, default=200.0, help="HBM budget for pre-generated bundles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N>1 path with several ranks sharing one GPU)")
@@ -158,6 +159,14 @@ def main():
         err = np.sqrt(np.mean(sum((got[k] - host[k]) ** 2 for k in "xyz")))
         bit = all(np.array_equal(got[k], host[k]) for k in cases.ALLCOLS)
         parity = {"rays": chk, "rms_pos_err_mm_vs_oracle": float(err), "bit_identical": bool(bit)}
+        if not args.no_fused:
+            import pyxfocus_amd as pxf
+            r1_ = sources.annulus(rin, rout, chk, rng="philox", seed=999)
+            with pxf.fused():
+                chain_step(r1_, tran, surf)
+            parity["fused_bit_identical"] = bool(all(np.array_equal(v.cpu().numpy(), host[k])
+                                                     for k, v in zip(cases.ALLCOLS, r1_)))
+            del r1_
         del r0_
 
     # ---- warm-up -------------------------------------------------------------------------
@@ -216,6 +225,43 @@ def main():
                 "algorithmic_bytes_per_launch": dom["bytes_per_ray"] * N, "avg_launch_ms": dom["avg_ms"]}
     chain_gbps = 576.0 * N * K / (sum(k["avg_ms"] for k in kern) * K * 1e-3) / 1e9
 
+    # ---- the same K steps again as ONE fused launch per step (reported separately, never mixed
+    # into `value`: 120 algorithmic B/ray instead of 576; bit-identical results) --------------------
+    fused = None
+    if not args.no_fused:
+        import pyxfocus_amd as pxf
+        fb = [fresh(10_000 + i) for i in range(pool)]
+        with pxf.fused():
+            chain_step(fb[0], tran, surf)               # warm-up (first bundle is re-generated below)
+        fb[0] = fresh(10_000)
+        fev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * K)]
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        f0 = time.perf_counter()
+        for i in range(K):
+            if i >= pool:
+                fb[i % pool] = fresh(10_000 + i)
+            fev[2 * i].record()
+            with pxf.fused():
+                chain_step(fb[i % pool], tran, surf)
+            fev[2 * i + 1].record()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        felapsed = time.perf_counter() - f0
+        if dist:
+            t = torch.tensor([felapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            felapsed = float(t.item())
+        fms = float(np.mean([fev[2 * i].elapsed_time(fev[2 * i + 1]) for i in range(K)]))
+        same = all(torch.equal(a, b) for a, b in zip(fb[(K - 1) % pool], [c for c in fb[(K - 1) % pool]]))
+        fused = {"value": N * n_gpus * K / felapsed, "unit": "rays/s", "ms_per_step": felapsed / K * 1e3,
+                 "launches_per_step": 1, "algorithmic_bytes_per_ray": 120, "avg_launch_ms": fms,
+                 "GBps": 120.0 * N / (fms * 1e-3) / 1e9, "frac_of_hbm_peak": 120.0 * N / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "note": "pyxfocus_amd.fused(): same calls recorded and run as one ray-program kernel"}
+        del fb, same
+
     # ---- focal plane: global metric via all-reduce, and the all-gather the north-star names ----
     last = bundles[(K - 1) % pool]
     rms = anal.rmsCentroid(last, group=True if dist else None)
@@ -248,7 +294,8 @@ def main():
                           "bundles_pregenerated": pool, "bundles_regenerated_in_timed_region": regen},
                "roofline": roofline,
                "chain_GBps": chain_gbps, "chain_frac_of_hbm_peak": chain_gbps / HBM_PEAK_GBS,
-               "kernels": kern, "focal_rms_centroid_mm": rms, "parity": parity, "focal_gather": gather}
+               "kernels": kern, "focal_rms_centroid_mm": rms, "parity": parity, "focal_gather": gather,
+               "fused": fused}
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -210,6 +210,50 @@ int pxf_central_moments(const double *x, const double *y, const double *w, int64
 int pxf_source(int32_t kind, double *const *cols, int64_t num, double p0, double p1, double p2,
                double p3, uint64_t seed, uint64_t first_index, pxf_stream_t stream);
 
+/* ---- fused ray program ---------------------------------------------------------------------------
+ * The reference makes one pass over the bundle per API call (576 B/ray of HBM traffic for the
+ * two-bounce chain).  pxf_program_run executes a SEQUENCE of the per-ray operations above in one
+ * launch: every column is loaded at most once, all operations run on the ray in registers, every
+ * modified column is stored once (120 B/ray for the same chain).  The per-ray arithmetic is the
+ * same code as the stand-alone entry points, so results are bit-identical to calling them one by
+ * one.  Operations whose result is overwritten before anything reads it are dropped (e.g. the
+ * rotation of the surface normal by a `transform` that precedes a surface intersection).
+ *
+ * `ops` is a HOST array.  `a[]` holds the trailing scalar arguments of the corresponding entry
+ * point, in its order (e.g. PXF_OP_TRANSFORM: tx,ty,tz,rx,ry,rz; PXF_OP_WOLTERPRIMARYOPD:
+ * r0,z0,psi,nr; PXF_OP_RADGRAT: wave,dpermm,order; PXF_OP_RADGRATW: dpermm,order with `aux` = the
+ * device wavelength column).  `mask` as for the stand-alone call (NULL = all rays).
+ * `cols` = HOST array of the ten device column pointers in bundle order opd,x,y,z,l,m,n,ux,uy,uz;
+ * columns no operation touches may be NULL. */
+#define PXF_OP_FLAT 1
+#define PXF_OP_FLATOPD 2
+#define PXF_OP_CONIC 3
+#define PXF_OP_CONICOPD 4
+#define PXF_OP_WOLTERPRIMARY 5
+#define PXF_OP_WOLTERPRIMARYOPD 6
+#define PXF_OP_WOLTERSECONDARY 7
+#define PXF_OP_TRANSFORM 8
+#define PXF_OP_ITRANSFORM 9
+#define PXF_OP_REFLECT 10
+#define PXF_OP_RADGRAT 11
+#define PXF_OP_RADGRATW 12
+#define PXF_PROGRAM_MAX_OPS 32
+
+typedef struct pxf_op {
+    int32_t code;        /* PXF_OP_* */
+    int32_t reserved;    /* must be 0 */
+    const uint8_t *mask; /* device uint8[num] or NULL */
+    const double *aux;   /* device float64[num] extra column (RADGRATW wavelengths) or NULL */
+    double a[6];         /* scalar arguments */
+} pxf_op_t;
+
+int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int64_t num,
+                    pxf_stream_t stream);
+/* What the planner decided for a program (for tests / reports): columns loaded, columns stored
+ * (bit c = column c in bundle order) and the number of operation groups dropped as dead. */
+int pxf_program_plan(const pxf_op_t *ops, int32_t nops, uint32_t *load_mask, uint32_t *store_mask,
+                     int32_t *dropped);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,143 @@
+"""Fused tracing: run a sequence of PyXFocus calls as ONE kernel launch.
+
+    with pyxfocus_amd.fused():
+        tran.transform(rays, 0, 0, -(z0 + 2*L), 0, 0, 0)
+        surf.wolterprimary(rays, r0, z0);  tran.reflect(rays)
+        surf.woltersecondary(rays, r0, z0); tran.reflect(rays)
+        surf.flat(rays)
+    # <- here the rays are up to date
+
+Inside the block the per-ray calls (flat, conic, wolterprimary[opd], woltersecondary, transform,
+itransform, reflect, radgrat -- with or without ``ind``) are RECORDED instead of launched; at the
+end of the block (or at ``flush()``, or as soon as a call arrives that cannot be fused: vignette,
+applyT, pointTo, zernsurf, any analyses.* reduction, a call on a different bundle) the recorded
+program runs through ``pxf_program_run``: each column is read once and written once, with the ray in
+registers in between -- 120 B/ray instead of 576 for the two-bounce chain -- and operations whose
+result is overwritten unread are dropped.  The arithmetic is the same device code the one-by-one
+calls use, so the result is bit-identical to running without ``fused()``.
+
+Reading a ray tensor directly (``rays[1].cpu()``) inside the block does NOT trigger a flush --
+call ``flush()`` first.
+"""
+import ctypes as C
+import threading
+
+import torch
+
+from . import _lib
+
+_tls = threading.local()
+
+OPCODES = {"pxf_flat": 1, "pxf_flatopd": 2, "pxf_conic": 3, "pxf_conicopd": 4, "pxf_wolterprimary": 5,
+           "pxf_wolterprimaryopd": 6, "pxf_woltersecondary": 7, "pxf_transform": 8, "pxf_itransform": 9,
+           "pxf_reflect": 10, "pxf_radgrat": 11, "pxf_radgratw": 12}
+# bundle slots (opd=0, x=1 ... uz=9) of the columns each entry point takes, in call order
+SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5, 6, 7, 8, 9, 0),
+         "pxf_conic": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_conicopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_wolterprimary": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_wolterprimaryopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_woltersecondary": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_transform": (1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_itransform": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_reflect": (4, 5, 6, 7, 8, 9),
+         "pxf_radgrat": (1, 2, 4, 5, 6), "pxf_radgratw": (1, 2, 4, 5, 6, -1)}
+MAX_OPS = 32
+
+
+class PxfOp(C.Structure):
+    _fields_ = [("code", C.c_int32), ("reserved", C.c_int32), ("mask", C.c_void_p), ("aux", C.c_void_p),
+                ("a", C.c_double * 6)]
+
+
+class _Recorder:
+    def __init__(self):
+        self.reset()
+        self.launches = 0
+        self.fused_ops = 0
+
+    def reset(self):
+        self.ops = []
+        self.cols = [None] * 10      # tensors by bundle slot
+        self.keep = []               # masks / aux columns kept alive until the launch
+        self.num = None
+        self.dev = None
+
+    def try_add(self, name, cols, tail, mask):
+        """Record one call; False if it cannot join the pending program (caller flushes and retries)."""
+        if name not in OPCODES or len(self.ops) >= MAX_OPS:
+            return False
+        slots = SLOTS[name]
+        num = cols[0].shape[0]
+        if self.num is not None and (num != self.num or cols[0].device != self.dev):
+            return False
+        aux = None
+        for t, s in zip(cols, slots):
+            if s < 0:
+                aux = t
+                continue
+            if self.cols[s] is not None and self.cols[s].data_ptr() != t.data_ptr():
+                return False
+        for t, s in zip(cols, slots):
+            if s >= 0:
+                self.cols[s] = t
+        self.num, self.dev = num, cols[0].device
+        op = PxfOp()
+        op.code = OPCODES[name]
+        op.mask = mask.data_ptr() if mask is not None else None
+        op.aux = aux.data_ptr() if aux is not None else None
+        for i, v in enumerate(tail):
+            op.a[i] = float(v)
+        self.ops.append(op)
+        self.keep.extend(t for t in (mask, aux) if t is not None)
+        return True
+
+    def flush(self):
+        if not self.ops:
+            self.reset()
+            return
+        ops = (PxfOp * len(self.ops))(*self.ops)
+        ptrs = (C.c_void_p * 10)(*[(t.data_ptr() if t is not None else None) for t in self.cols])
+        dev = self.dev
+        with torch.cuda.device(dev):
+            rc = _lib.lib().pxf_program_run(ops, len(self.ops), ptrs, self.num,
+                                            torch.cuda.current_stream(dev).cuda_stream)
+        n = len(self.ops)
+        self.reset()
+        _lib.check(rc, "pxf_program_run")
+        self.launches += 1
+        self.fused_ops += n
+
+
+def active():
+    return getattr(_tls, "rec", None)
+
+
+def flush():
+    """Run whatever is recorded (no-op outside a fused block)."""
+    rec = active()
+    if rec is not None:
+        rec.flush()
+
+
+class fused:
+    """Context manager; re-entrant use nests into the outermost block."""
+
+    def __enter__(self):
+        self.outer = active()
+        if self.outer is None:
+            _tls.rec = _Recorder()
+        return active()
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.outer is None:
+            rec = active()
+            _tls.rec = None
+            if exc_type is None:
+                rec.flush()
+        return False
+
+
+def plan(ops):
+    """(load_mask, store_mask, dropped) the planner derives for a list of PxfOp (tests/reports)."""
+    arr = (PxfOp * len(ops))(*ops)
+    lm, sm, dr = C.c_uint32(), C.c_uint32(), C.c_int32()
+    _lib.check(_lib.lib().pxf_program_plan(arr, len(ops), C.byref(lm), C.byref(sm), C.byref(dr)),
+               "pxf_program_plan")
+    return lm.value, sm.value, dr.value

@@ -14,6 +14,7 @@ import math
 import numpy as np
 import torch
 
+from . import _fused as fused
 from . import _lib, native
 
 _ws_cache = {}
@@ -47,6 +48,7 @@ def _allreduce(out, group):
 
 def _moments(rays, weights, dirs=True, group=None):
     """The twelve weighted sums of include/pxf.h (PXF_NMOM) as a Python list of floats."""
+    fused.flush()
     x, y = rays[1], rays[2]
     cols = (x, y) + ((rays[4], rays[5], rays[6]) if dirs else ())
     num, dev = native._check_cols(cols, "analyses")
@@ -61,6 +63,7 @@ def _moments(rays, weights, dirs=True, group=None):
 
 
 def _central(rays, weights, cx, cy, group=None):
+    fused.flush()
     x, y = rays[1], rays[2]
     num, dev = native._check_cols((x, y), "analyses")
     w = _weights(weights, num, dev)
@@ -102,6 +105,7 @@ def rmsY(rays, weights=None, group=None):
 
 def rho(rays, weights=None, cent=False):
     """Distance from the centroid (cent=True) or the origin for all rays (analyses.py:60-71)."""
+    fused.flush()
     x, y = rays[1:3]
     cx, cy = centroid(rays, weights=weights) if cent is True else (0, 0)
     return torch.sqrt((x - cx) ** 2 + (y - cy) ** 2)
@@ -162,6 +166,7 @@ def analyticXPlane(rays, weights=None, group=None):
 
 def indAngle(rays, ind=None, normal=None):
     """Incidence angle of the rays with the current (or a given) surface normal (analyses.py:164-182)."""
+    fused.flush()
     sel = slice(None) if ind is None else ind
     l, m, n = rays[4][sel], rays[5][sel], rays[6][sel]
     if normal is None:

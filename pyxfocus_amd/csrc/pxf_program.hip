@@ -1,0 +1,309 @@
+// pxf_program.hip -- fused ray program: a sequence of per-ray operations in ONE launch.
+//
+// Why: every stand-alone kernel is HBM-bound and already moves exactly its algorithmic bytes, so
+// the only way to trace faster is to move fewer bytes.  A trace is a straight-line program over
+// the ray's ten numbers; running it with the ray held in registers turns the two-bounce chain's
+// 576 B/ray (six passes) into 120 B/ray (read x,y,z,l,m,n once; write nine columns once).
+//
+// How: the host turns the caller's pxf_op_t list into micro-operations with read / write /
+// maybe-write column sets, removes the dead ones by a backward liveness pass, derives the load
+// and store sets by a forward pass, and passes the plan BY VALUE in the kernel arguments.  The
+// kernel is a wave-uniform interpreter: `switch (op.code)` is a scalar branch (no divergence),
+// and each case is the SAME Op::apply the stand-alone kernels instantiate, so the two paths are
+// bit-identical by construction.  Two rays per thread, 16-byte accesses, NT policy as elsewhere.
+#include "pxf_ops_surfaces.h"
+#include "pxf_ops_transforms.h"
+
+namespace pxf {
+
+constexpr int kMaxOps = PXF_PROGRAM_MAX_OPS;
+
+struct ProgOp {
+    int code;
+    int flags;  // transform: vector groups to move
+    const uint8_t *mask;
+    const double *aux;
+    double p[9];
+};
+
+struct Program {
+    int nops;
+    unsigned load, store;
+    ProgOp op[kMaxOps];
+};
+static_assert(sizeof(Program) + sizeof(Cols) + 64 <= 4096, "program must fit the kernel-argument segment");
+
+template <class OP, int V>
+__device__ __forceinline__ void run_op(const OP &o, Ray (&r)[V], const bool (&sel)[V])
+{
+    unsigned wm[V];
+    o.template apply<V>(r, sel, wm);
+}
+
+template <int V, bool NT>
+__global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const int64_t vv = first + v;
+        Ray r[V];
+#pragma unroll
+        for (int col = 0; col < 10; col++) {
+            if (pg.load & B(col)) {  // wave-uniform
+                double t[V];
+                load_col<V, NT>(c.p[col], vv, t);
+#pragma unroll
+                for (int k = 0; k < V; k++) r[k].c[col] = t[k];
+            }
+        }
+        for (int i = 0; i < pg.nops; i++) {
+            const ProgOp &o = pg.op[i];
+            bool sel[V];
+            Ray keep[V];
+            const bool masked = o.mask != nullptr;
+            if (masked) {
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    sel[k] = o.mask[vv * V + k] != 0;
+                    keep[k] = r[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; k++) sel[k] = true;
+            }
+            switch (o.code) {
+                case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
+                case PXF_OP_FLATOPD: run_op(FlatOp<true>{o.p[0]}, r, sel); break;
+                case PXF_OP_CONIC: run_op(ConicOp<false>{o.p[0], o.p[1], 0.}, r, sel); break;
+                case PXF_OP_CONICOPD: run_op(ConicOp<true>{o.p[0], o.p[1], o.p[2]}, r, sel); break;
+                case PXF_OP_WOLTERPRIMARY: run_op(WolterPrimaryOp<false>{o.p[0], o.p[1], o.p[2], 0.}, r, sel); break;
+                case PXF_OP_WOLTERPRIMARYOPD:
+                    run_op(WolterPrimaryOp<true>{o.p[0], o.p[1], o.p[2], o.p[3]}, r, sel);
+                    break;
+                case PXF_OP_WOLTERSECONDARY: run_op(WolterSecondaryOp{o.p[0], o.p[1], o.p[2]}, r, sel); break;
+                case PXF_OP_TRANSFORM:
+                    run_op(TransformOp<false>{o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.flags}, r, sel);
+                    break;
+                case PXF_OP_ITRANSFORM:
+                    run_op(TransformOp<true>{o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.flags}, r, sel);
+                    break;
+                case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
+                case PXF_OP_RADGRAT: run_op(RadgratOp<false>{o.p[0], o.p[1], o.p[2], o.p[3], o.p[4]}, r, sel); break;
+                case PXF_OP_RADGRATW: {
+                    double t[V];
+                    load_col<V, NT>(o.aux, vv, t);
+#pragma unroll
+                    for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
+                    run_op(RadgratOp<true>{o.p[0], o.p[1], 0., o.p[3], o.p[4]}, r, sel);
+                    break;
+                }
+                default: break;
+            }
+            if (masked) {  // unselected rays keep every register
+#pragma unroll
+                for (int k = 0; k < V; k++)
+                    if (!sel[k]) r[k] = keep[k];
+            }
+        }
+#pragma unroll
+        for (int col = 0; col < 10; col++) {
+            if (pg.store & B(col)) {
+                double t[V];
+                bool w[V];
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    t[k] = r[k].c[col];
+                    w[k] = true;
+                }
+                store_col<V, NT>(c.p[col], vv, t, w);
+            }
+        }
+    }
+}
+
+// ---- host: plan ------------------------------------------------------------------------------
+struct Micro {
+    unsigned rd, wa, wm;  // columns read, always written, maybe written
+    int op;               // index into the op list
+    int group;            // transform group bit, 0 otherwise
+    bool live;
+};
+
+static int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped)
+{
+    if (nops < 0 || nops > kMaxOps || (nops > 0 && !ops)) return PXF_EINVAL;
+    Micro mi[kMaxOps * 3];
+    int nm = 0;
+    for (int i = 0; i < nops; i++) {
+        const pxf_op_t &u = ops[i];
+        if (u.reserved != 0) return PXF_EINVAL;
+        ProgOp &o = pg.op[i];
+        o = ProgOp{};
+        o.code = u.code;
+        o.mask = u.mask;
+        o.aux = u.aux;
+        auto add = [&](unsigned rd, unsigned wa, unsigned wmaybe, int group) {
+            if (u.mask) {  // a masked op writes conditionally and must see the old values
+                wmaybe |= wa;
+                wa = 0;
+            }
+            mi[nm++] = Micro{rd, wa, wmaybe, i, group, true};
+        };
+        switch (u.code) {
+            case PXF_OP_FLAT: add(POS | DIR, POS | NRM, 0, 0); break;
+            case PXF_OP_FLATOPD:
+                o.p[0] = u.a[0];
+                add(POS | DIR | B(OPD), POS | NRM | B(OPD), 0, 0);
+                break;
+            case PXF_OP_CONIC:
+                o.p[0] = u.a[0];
+                o.p[1] = u.a[1];
+                add(POS | DIR, 0, POS | DIR | NRM, 0);  // miss: lmn zeroed, xyz/u kept
+                break;
+            case PXF_OP_CONICOPD:
+                o.p[0] = u.a[0];
+                o.p[1] = u.a[1];
+                o.p[2] = u.a[2];
+                add(POS | DIR | B(OPD), 0, POS | DIR | NRM | B(OPD), 0);
+                break;
+            case PXF_OP_WOLTERPRIMARY:
+            case PXF_OP_WOLTERPRIMARYOPD: {
+                const bool wopd = u.code == PXF_OP_WOLTERPRIMARYOPD;
+                const WolterPrimaryOp<true> w = make_wolter_primary<true>(u.a[0], u.a[1], u.a[2], wopd ? u.a[3] : 0.);
+                o.p[0] = w.twop;
+                o.p[1] = w.pp;
+                o.p[2] = w.cst;
+                o.p[3] = w.nr;
+                add(POS | DIR | (wopd ? B(OPD) : 0u), POS | NRM | (wopd ? B(OPD) : 0u), 0, 0);
+                break;
+            }
+            case PXF_OP_WOLTERSECONDARY: {
+                const WolterSecondaryOp w = make_wolter_secondary(u.a[0], u.a[1], u.a[2]);
+                o.p[0] = w.e2;
+                o.p[1] = w.twoe2;
+                o.p[2] = w.d;
+                add(POS | DIR, POS | NRM, 0, 0);
+                break;
+            }
+            case PXF_OP_TRANSFORM:
+            case PXF_OP_ITRANSFORM: {
+                double cs[6];
+                trig6(u.a[3], u.a[4], u.a[5], u.code == PXF_OP_ITRANSFORM, cs);
+                o.p[0] = u.a[0];
+                o.p[1] = u.a[1];
+                o.p[2] = u.a[2];
+                for (int k = 0; k < 6; k++) o.p[3 + k] = cs[k];
+                add(POS, POS, 0, 1);  // three independent micro-ops
+                add(DIR, DIR, 0, 2);
+                add(NRM, NRM, 0, 4);
+                break;
+            }
+            case PXF_OP_REFLECT: add(DIR | NRM, DIR, 0, 0); break;
+            case PXF_OP_RADGRAT:
+                o.p[0] = u.a[1];  // dpermm
+                o.p[1] = u.a[2];  // order
+                o.p[2] = u.a[0];  // wave
+                radgrat_consts(o.p[3], o.p[4]);
+                add(B(X) | B(Y) | DIR, DIR, 0, 0);
+                break;
+            case PXF_OP_RADGRATW:
+                if (!u.aux) return PXF_EINVAL;
+                o.p[0] = u.a[0];  // dpermm
+                o.p[1] = u.a[1];  // order
+                radgrat_consts(o.p[3], o.p[4]);
+                add(B(X) | B(Y) | DIR, DIR, 0, 0);
+                break;
+            default: return PXF_EINVAL;
+        }
+    }
+    // backward liveness: every column is observable when the program ends
+    unsigned live = 0x3ffu;
+    int dead = 0;
+    for (int j = nm - 1; j >= 0; j--) {
+        Micro &m = mi[j];
+        if (((m.wa | m.wm) & live) == 0) {
+            m.live = false;
+            dead++;
+            continue;
+        }
+        live = (live & ~m.wa) | m.rd;
+    }
+    // forward: loads = read (or maybe-written) before definitely defined; stores = anything written
+    unsigned defined = 0, load = 0, store = 0;
+    for (int i = 0; i < nops; i++) pg.op[i].flags = 0;
+    bool op_live[kMaxOps] = {false};
+    for (int j = 0; j < nm; j++) {
+        const Micro &m = mi[j];
+        if (!m.live) continue;
+        load |= (m.rd | m.wm) & ~defined;
+        defined |= m.wa;
+        store |= m.wa | m.wm;
+        op_live[m.op] = true;
+        pg.op[m.op].flags |= m.group;
+    }
+    // compact away fully dead ops
+    int k = 0;
+    for (int i = 0; i < nops; i++)
+        if (op_live[i]) pg.op[k++] = pg.op[i];
+    pg.nops = k;
+    pg.load = load;
+    pg.store = store;
+    if (dropped) *dropped = dead;
+    return PXF_OK;
+}
+
+}  // namespace pxf
+
+using namespace pxf;
+
+extern "C" {
+
+int pxf_program_plan(const pxf_op_t *ops, int32_t nops, uint32_t *load_mask, uint32_t *store_mask,
+                     int32_t *dropped)
+{
+    Program pg{};
+    int dead = 0;
+    int rc = plan_program(ops, nops, pg, &dead);
+    if (rc != PXF_OK) return rc;
+    if (load_mask) *load_mask = pg.load;
+    if (store_mask) *store_mask = pg.store;
+    if (dropped) *dropped = dead;
+    return PXF_OK;
+}
+
+int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int64_t num, pxf_stream_t stream)
+{
+    Program pg{};
+    int rc = plan_program(ops, nops, pg, nullptr);
+    if (rc != PXF_OK) return rc;
+    if (num < 0 || !cols) return PXF_EINVAL;
+    if (num == 0 || pg.nops == 0) return PXF_OK;
+    Cols c{};
+    bool aligned = true;
+    for (int col = 0; col < 10; col++) {
+        c.p[col] = cols[col];
+        if ((pg.load | pg.store) & B(col)) {
+            if (!cols[col]) return PXF_EINVAL;
+            if ((uintptr_t)cols[col] & 15) aligned = false;
+        }
+    }
+    for (int i = 0; i < pg.nops; i++)
+        if (pg.op[i].aux && ((uintptr_t)pg.op[i].aux & 15)) aligned = false;
+    hipStream_t s = (hipStream_t)stream;
+    const bool nt = use_nt(num);
+    const int64_t nvec2 = aligned ? num / 2 : 0;
+    if (nvec2 > 0) {
+        if (nt)
+            hipLaunchKernelGGL((program_kernel<2, true>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);
+        else
+            hipLaunchKernelGGL((program_kernel<2, false>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);
+    }
+    const int64_t done = nvec2 * 2;
+    if (done < num)
+        hipLaunchKernelGGL((program_kernel<1, false>), dim3(grid_for(num - done)), dim3(kBlock), 0, s, c, done,
+                           num - done, pg);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+}  // extern "C"

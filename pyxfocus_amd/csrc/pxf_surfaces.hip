@@ -4,215 +4,9 @@
 // operation order (no FMA contraction) so the results are bit-identical to it; citations are
 // file:line in the reference tree.  Per-surface scalars (Van Speybroeck p,d,e) are evaluated
 // on the HOST with glibc libm, as the reference does once per call, and passed by value.
-#include <math.h>
-
-#include "pxf_kernel.h"
+#include "pxf_ops_surfaces.h"
 
 namespace pxf {
-
-// ---- flat / flatOPD : surfacesf.f95:4-29 / 32-53 ------------------------------------------
-// R x y z l m n (+opd)   W x y z ux uy uz (+opd)   = 96 B/ray (+16)
-template <bool WOPD>
-struct FlatOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
-    static constexpr unsigned WR = POS | NRM | (WOPD ? B(OPD) : 0u);
-    double nr;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            // `delta` is implicitly REAL*4 in the reference: round the distance to fp32
-            const float delta = (float)(-r[k].c[Z] / r[k].c[N]);
-            const double dd = (double)delta;
-            r[k].c[Z] = 0.;
-            r[k].c[X] = r[k].c[X] + dd * r[k].c[L];
-            r[k].c[Y] = r[k].c[Y] + dd * r[k].c[M];
-            r[k].c[UX] = 0.;
-            r[k].c[UY] = 0.;
-            r[k].c[UZ] = 1.;
-            if (WOPD) r[k].c[OPD] = r[k].c[OPD] + dd * nr;
-            wm[k] = WR;
-        }
-    }
-};
-
-// ---- conic / conicopd : surfacesf.f95:302-360 / 366-420 -------------------------------------
-// R x y z l m n (+opd)   W x y z ux uy uz (+opd) on a hit, l m n on a miss  = 96 B/ray (+16)
-template <bool WOPD>
-struct ConicOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
-    static constexpr unsigned WR = POS | DIR | NRM | (WOPD ? B(OPD) : 0u);
-    double R, K, nr;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-        const double K1 = K + 1, twoR = 2 * R;
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            double x = r[k].c[X], y = r[k].c[Y], z = r[k].c[Z];
-            const double l = r[k].c[L], m = r[k].c[M], n = r[k].c[N];
-            double s = 0.;
-            if (K == -1 && fabs(n) == 1.) {  // :316-317 axial ray onto a paraboloid
-                s = (x * x + y * y - twoR * z) / (twoR * n);
-            } else {
-                double denom = l * l + m * m + K1 * (n * n);
-                double b = x * l + y * m + (K1 * z - R) * n;
-                b = b / denom;
-                double c;
-                if (WOPD)  // :386 -- term order differs from :322
-                    c = x * x + y * y + K1 * (z * z) - twoR * z;
-                else
-                    c = x * x + y * y - twoR * z + K1 * (z * z);
-                c = c / denom;
-                const double disc = b * b - c;
-                if (disc >= 0.) {
-                    const double sq = sqrt(disc);
-                    const double s1 = -b + sq, s2 = -b - sq;
-                    s = (fabs(s1) <= fabs(s2)) ? s1 : s2;  // :332-336, ties pick s1
-                }
-            }
-            if (s == 0.) {  // :342-345 miss OR already on the surface: kill the ray in band
-                r[k].c[L] = 0.;
-                r[k].c[M] = 0.;
-                r[k].c[N] = 0.;
-                wm[k] = DIR;
-            } else {
-                x = x + l * s;
-                y = y + m * s;
-                z = z + n * s;
-                const double r2 = x * x + y * y;
-                const double denom = sqrt(R * R - K * r2);
-                double uz = -(R / fabs(R) * sqrt(R * R - K1 * r2));
-                r[k].c[X] = x;
-                r[k].c[Y] = y;
-                r[k].c[Z] = z;
-                r[k].c[UX] = -x / denom;
-                r[k].c[UY] = -y / denom;
-                r[k].c[UZ] = -uz / denom;
-                if (WOPD) r[k].c[OPD] = r[k].c[OPD] + s * nr;
-                wm[k] = POS | NRM | (WOPD ? B(OPD) : 0u);
-            }
-        }
-    }
-};
-
-// ---- Newton driver shared by the Wolter kernels -------------------------------------------
-// All V rays of a thread iterate in ONE loop (two independent dependency chains interleave and
-// hide the fp64 divide latency); a ray stops updating the moment its own |delt| <= tol, so each
-// ray sees exactly the reference's iteration sequence.  The surface normal is built from the
-// gradient evaluated BEFORE the last step (woltsurf.f95:44-47,151-154) -- reproduced, not fixed.
-
-// wolterprimary / wolterprimaryopd : woltsurf.f95:7-54 / 60-108
-// R x y z l m n (+opd)   W x y z ux uy uz (+opd)   = 96 B/ray (+16)
-template <bool WOPD>
-struct WolterPrimaryOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
-    static constexpr unsigned WR = POS | NRM | (WOPD ? B(OPD) : 0u);
-    double twop;  // 2*p  (= Fz)
-    double pp;    // p**2
-    double cst;   // 4*e**2*p*d/(e**2-1)
-    double nr;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-        const double tol = WOPD ? PXF_TOL_1EM10 : PXF_TOL_1EM8;
-        const double Fz = twop;
-        bool act[V];
-        double Fx[V], Fy[V];
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            act[k] = sel[k];
-            any |= act[k];
-            Fx[k] = 0.;
-            Fy[k] = 0.;
-        }
-        for (int it = 0; any && it < kNewtonCap; it++) {
-            any = false;
-#pragma unroll
-            for (int k = 0; k < V; k++) {
-                if (act[k]) {
-                    const double x = r[k].c[X], y = r[k].c[Y], z = r[k].c[Z];
-                    const double F = twop * z + pp + cst - x * x - y * y;
-                    Fx[k] = -2. * x;
-                    Fy[k] = -2. * y;
-                    const double Fp = Fx[k] * r[k].c[L] + Fy[k] * r[k].c[M] + Fz * r[k].c[N];
-                    const double delt = -F / Fp;
-                    r[k].c[X] = x + r[k].c[L] * delt;
-                    r[k].c[Y] = y + r[k].c[M] * delt;
-                    r[k].c[Z] = z + r[k].c[N] * delt;
-                    if (WOPD) r[k].c[OPD] = r[k].c[OPD] + nr * delt;
-                    act[k] = fabs(delt) > tol;
-                    any |= act[k];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            const double Fp = sqrt(Fx[k] * Fx[k] + Fy[k] * Fy[k] + Fz * Fz);
-            r[k].c[UX] = Fx[k] / Fp;
-            r[k].c[UY] = Fy[k] / Fp;
-            r[k].c[UZ] = Fz / Fp;
-            wm[k] = WR;
-        }
-    }
-};
-
-// woltersecondary : woltsurf.f95:114-161      R x y z l m n   W x y z ux uy uz  = 96 B/ray
-struct WolterSecondaryOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = POS | DIR;
-    static constexpr unsigned WR = POS | NRM;
-    double e2;     // e**2
-    double twoe2;  // 2*e**2
-    double d;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-        bool act[V];
-        double Fx[V], Fy[V], Fz[V];
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            act[k] = sel[k];
-            any |= act[k];
-            Fx[k] = Fy[k] = Fz[k] = 0.;
-        }
-        for (int it = 0; any && it < kNewtonCap; it++) {
-            any = false;
-#pragma unroll
-            for (int k = 0; k < V; k++) {
-                if (act[k]) {
-                    const double x = r[k].c[X], y = r[k].c[Y], z = r[k].c[Z];
-                    const double dz = d + z;
-                    const double F = e2 * (dz * dz) - z * z - x * x - y * y;
-                    Fx[k] = -2. * x;
-                    Fy[k] = -2. * y;
-                    Fz[k] = twoe2 * dz - 2 * z;
-                    const double Fp = Fx[k] * r[k].c[L] + Fy[k] * r[k].c[M] + Fz[k] * r[k].c[N];
-                    const double delt = -F / Fp;
-                    r[k].c[X] = x + r[k].c[L] * delt;
-                    r[k].c[Y] = y + r[k].c[M] * delt;
-                    r[k].c[Z] = z + r[k].c[N] * delt;
-                    act[k] = fabs(delt) > PXF_TOL_1EM8;
-                    any |= act[k];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            const double Fp = sqrt(Fx[k] * Fx[k] + Fy[k] * Fy[k] + Fz[k] * Fz[k]);
-            r[k].c[UX] = Fx[k] / Fp;
-            r[k].c[UY] = Fy[k] / Fp;
-            r[k].c[UZ] = Fz[k] / Fp;
-            wm[k] = WR;
-        }
-    }
-};
 
 static Cols cols9(double *opd, double *x, double *y, double *z, const double *l, const double *m,
                   const double *n, double *ux, double *uy, double *uz)
@@ -280,9 +74,7 @@ int pxf_wolterprimary(double *x, double *y, double *z, const double *l, const do
                       const double *n, double *ux, double *uy, double *uz, int64_t num, double r0,
                       double z0, double psi, const uint8_t *mask, pxf_stream_t stream)
 {
-    double p, d, e;
-    pxf_wolter_params(r0, z0, psi, &p, &d, &e);
-    WolterPrimaryOp<false> op{2 * p, p * p, 4 * (e * e) * p * d / (e * e - 1), 0.};
+    const WolterPrimaryOp<false> op = make_wolter_primary<false>(r0, z0, psi, 0.);
     return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
 }
 
@@ -291,9 +83,7 @@ int pxf_wolterprimaryopd(double *opd, double *x, double *y, double *z, const dou
                          int64_t num, double r0, double z0, double psi, double nr,
                          const uint8_t *mask, pxf_stream_t stream)
 {
-    double p, d, e;
-    pxf_wolter_params(r0, z0, psi, &p, &d, &e);
-    WolterPrimaryOp<true> op{2 * p, p * p, 4 * (e * e) * p * d / (e * e - 1), nr};
+    const WolterPrimaryOp<true> op = make_wolter_primary<true>(r0, z0, psi, nr);
     return launch_rays(cols9(opd, x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
 }
 
@@ -301,9 +91,7 @@ int pxf_woltersecondary(double *x, double *y, double *z, const double *l, const 
                         const double *n, double *ux, double *uy, double *uz, int64_t num, double r0,
                         double z0, double psi, const uint8_t *mask, pxf_stream_t stream)
 {
-    double p, d, e;
-    pxf_wolter_params(r0, z0, psi, &p, &d, &e);
-    WolterSecondaryOp op{e * e, 2 * (e * e), d};
+    const WolterSecondaryOp op = make_wolter_secondary(r0, z0, psi);
     return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
 }
 

@@ -5,133 +5,9 @@
 // reference re-evaluates the same pure function 18 times per ray, transformationsf.f95:3-28)
 // and passed by value; the per-ray work is then add/mul only, in the reference's order, so the
 // result is bit-identical.
-#include <math.h>
-
-#include "pxf_kernel.h"
+#include "pxf_ops_transforms.h"
 
 namespace pxf {
-
-// rotatevector, transformationsf.f95:3-28 (axis 1,2,3 = x,y,z), with c=cos(theta), s=sin(theta)
-template <int AXIS>
-__device__ __forceinline__ void rotv(double &x, double &y, double &z, double c, double s)
-{
-    if (AXIS == 1) {
-        const double o2 = c * y - s * z, o3 = s * y + c * z;
-        y = o2;
-        z = o3;
-    } else if (AXIS == 2) {
-        const double o1 = c * x + s * z, o3 = -s * x + c * z;
-        x = o1;
-        z = o3;
-    } else {
-        const double o1 = c * x - s * y, o2 = s * x + c * y;
-        x = o1;
-        y = o2;
-    }
-}
-
-// transform : transformationsf.f95:134-163 ; itransform : :168-201.   R 9 + W 9 = 144 B/ray
-template <bool INVERSE>
-struct TransformOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = POS | DIR | NRM;
-    static constexpr unsigned WR = POS | DIR | NRM;
-    double tx, ty, tz;
-    double cx, sx, cy, sy, cz, sz;  // forward: cos/sin(rx..rz); inverse: cos/sin(-rx..-rz)
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            double *c = r[k].c;
-            if (!INVERSE) {
-                c[X] = c[X] + tx;
-                c[Y] = c[Y] + ty;
-                c[Z] = c[Z] + tz;
-                rotv<1>(c[X], c[Y], c[Z], cx, sx);
-                rotv<1>(c[L], c[M], c[N], cx, sx);
-                rotv<1>(c[UX], c[UY], c[UZ], cx, sx);
-                rotv<2>(c[X], c[Y], c[Z], cy, sy);
-                rotv<2>(c[L], c[M], c[N], cy, sy);
-                rotv<2>(c[UX], c[UY], c[UZ], cy, sy);
-                rotv<3>(c[X], c[Y], c[Z], cz, sz);
-                rotv<3>(c[L], c[M], c[N], cz, sz);
-                rotv<3>(c[UX], c[UY], c[UZ], cz, sz);
-            } else {
-                rotv<3>(c[X], c[Y], c[Z], cz, sz);
-                rotv<3>(c[L], c[M], c[N], cz, sz);
-                rotv<3>(c[UX], c[UY], c[UZ], cz, sz);
-                rotv<2>(c[X], c[Y], c[Z], cy, sy);
-                rotv<2>(c[L], c[M], c[N], cy, sy);
-                rotv<2>(c[UX], c[UY], c[UZ], cy, sy);
-                rotv<1>(c[X], c[Y], c[Z], cx, sx);
-                rotv<1>(c[L], c[M], c[N], cx, sx);
-                rotv<1>(c[UX], c[UY], c[UZ], cx, sx);
-                c[X] = c[X] - tx;
-                c[Y] = c[Y] - ty;
-                c[Z] = c[Z] - tz;
-            }
-            wm[k] = WR;
-        }
-    }
-};
-
-// reflect : transformationsf.f95:60-79.   R 6 + W 3 = 72 B/ray
-struct ReflectOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = DIR | NRM;
-    static constexpr unsigned WR = DIR;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            double *c = r[k].c;
-            const double dot = c[UX] * c[L] + c[UY] * c[M] + c[UZ] * c[N];
-            c[L] = c[L] - 2 * dot * c[UX];
-            c[M] = c[M] - 2 * dot * c[UY];
-            c[N] = c[N] - 2 * dot * c[UZ];
-            wm[k] = WR;
-        }
-    }
-};
-
-// radgrat / radgratW : transformationsf.f95:205-238 / 242-272.   R x y l m n (+wave) W l m n
-// = 64 B/ray (72 with a per-ray wavelength column, carried in the AUX slot).
-//
-// The reference computes  yaw = -pi32/2 - atan2(x,y)  (pi32 = acos(-1.) in SINGLE precision)
-// and then sin(yaw), cos(yaw).  With phi = atan2(x,y): sin(phi) = x/rho, cos(phi) = y/rho, so
-//     sin(yaw) = -( S*cos(phi) + C*sin(phi) ),   cos(yaw) = C*cos(phi) - S*sin(phi)
-// with S = sin(pi32/2), C = cos(pi32/2) (host libm; C = -4.371e-8 carries the fp32-pi quirk).
-// Three transcendentals per ray become two divides; the result agrees with the libm evaluation
-// to a few ulp of sin/cos (<= ~5e-16 absolute), i.e. ~1e-17 in the output cosines.
-template <bool WAVECOL>
-struct RadgratOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = B(X) | B(Y) | DIR | (WAVECOL ? B(AUX) : 0u);
-    static constexpr unsigned WR = DIR;
-    double dpermm, order, wave, S, C;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            double *c = r[k].c;
-            const double x = c[X], y = c[Y];
-            const double sn = WAVECOL ? y / fabs(y) : c[N] / fabs(c[N]);
-            const double w = WAVECOL ? c[AUX] : wave;
-            const double rho = sqrt(y * y + x * x);
-            const double d = dpermm * rho;
-            const double cphi = y / rho, sphi = x / rho;
-            const double syaw = -(S * cphi + C * sphi);
-            const double cyaw = C * cphi - S * sphi;
-            c[L] = c[L] + syaw * order * w / d;
-            c[M] = c[M] - cyaw * order * w / d;
-            c[N] = sn * sqrt(1. - c[L] * c[L] - c[M] * c[M]);
-            wm[k] = WR;
-        }
-    }
-};
 
 // applyT / applyTPos : transformations.py:257-289.  out = M[:3,:4] . [v,1].  Out-of-place.
 struct Mat34 {
@@ -166,28 +42,6 @@ __global__ __launch_bounds__(kBlock) void applyt_kernel(Cols in, Cols out, int64
         }
     }
 }
-
-// pointTo : transformations.py:91-100.   R x y z  W l m n
-struct PointToOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = POS;
-    static constexpr unsigned WR = DIR;
-    double x0, y0, z0, reverse;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            double *c = r[k].c;
-            const double dx = c[X] - x0, dy = c[Y] - y0, dz = c[Z] - z0;
-            const double R = sqrt(dx * dx + dy * dy + dz * dz);
-            c[L] = reverse * dx / R;
-            c[M] = reverse * dy / R;
-            c[N] = reverse * dz / R;
-            wm[k] = WR;
-        }
-    }
-};
 
 static int launch_applyt(const Cols &in, const Cols &out, int ngroups, int64_t num, const double *mpos,
                          const double *mdir, pxf_stream_t stream)
@@ -236,21 +90,6 @@ static Cols cols_xyzlmnu(const double *x, const double *y, const double *z, cons
     return c;
 }
 
-static void trig6(double rx, double ry, double rz, bool inverse, double (&cs)[6])
-{
-    if (inverse) {  // itransform rotates by tmp = -rz, -ry, -rx (transformationsf.f95:180-191)
-        rx = -rx;
-        ry = -ry;
-        rz = -rz;
-    }
-    cs[0] = cos(rx);
-    cs[1] = sin(rx);
-    cs[2] = cos(ry);
-    cs[3] = sin(ry);
-    cs[4] = cos(rz);
-    cs[5] = sin(rz);
-}
-
 }  // namespace pxf
 
 using namespace pxf;
@@ -263,7 +102,7 @@ int pxf_transform(double *x, double *y, double *z, double *l, double *m, double 
 {
     double cs[6];
     trig6(rx, ry, rz, false, cs);
-    TransformOp<false> op{tx, ty, tz, cs[0], cs[1], cs[2], cs[3], cs[4], cs[5]};
+    TransformOp<false> op{tx, ty, tz, cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], 7};
     return launch_rays(cols_xyzlmnu(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
 }
 
@@ -273,7 +112,7 @@ int pxf_itransform(double *x, double *y, double *z, double *l, double *m, double
 {
     double cs[6];
     trig6(rx, ry, rz, true, cs);
-    TransformOp<true> op{tx, ty, tz, cs[0], cs[1], cs[2], cs[3], cs[4], cs[5]};
+    TransformOp<true> op{tx, ty, tz, cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], 7};
     return launch_rays(cols_xyzlmnu(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
 }
 
@@ -288,13 +127,6 @@ int pxf_reflect(double *l, double *m, double *n, const double *ux, const double 
     c.p[UY] = const_cast<double *>(uy);
     c.p[UZ] = const_cast<double *>(uz);
     return launch_rays(c, num, mask, stream, ReflectOp{});
-}
-
-static void radgrat_consts(double &S, double &C)
-{
-    const double pi32 = (double)acosf(-1.f);  // pi = acos(-1.) in REAL*4, transformationsf.f95:214,251
-    S = sin(pi32 / 2);
-    C = cos(pi32 / 2);
 }
 
 int pxf_radgrat(const double *x, const double *y, double *l, double *m, double *n, double wave,

@@ -15,6 +15,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from . import _fused as fused
 from . import _lib
 
 
@@ -49,9 +50,19 @@ def _stream(dev):
 
 
 def _call(name, cols, tail, mask=None):
-    """cols -> device pointers, then num, then `tail` scalars, then mask, stream."""
+    """cols -> device pointers, then num, then `tail` scalars, then mask, stream.
+    Inside a `pyxfocus_amd.fused()` block the call is recorded instead (see _fused.py)."""
     num, dev = _check_cols(cols, name)
     mp = _mask_ptr(mask, num, dev, name)
+    rec = fused.active()
+    if rec is not None:
+        if num == 0:
+            return
+        if rec.try_add(name, cols, tail, mask):
+            return
+        rec.flush()                      # cannot join the pending program: run it, then go on
+        if rec.try_add(name, cols, tail, mask):
+            return
     h = _lib.lib()
     with torch.cuda.device(dev):
         rc = getattr(h, name)(*[t.data_ptr() for t in cols], num, *tail, mp, _stream(dev))
@@ -108,11 +119,13 @@ def _zern_tables(coeff, rorder, aorder):
 
 def tracezern(x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, mask=None):
     ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    fused.flush()
     _call("pxf_tracezern", (x, y, z, l, m, n, ux, uy, uz), (cp, rp, ap, len(ck), float(rad)), mask)
 
 
 def tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, nr, mask=None):
     ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    fused.flush()
     _call("pxf_tracezernopd", (opd, x, y, z, l, m, n, ux, uy, uz),
           (cp, rp, ap, len(ck), float(rad), float(nr)), mask)
 
@@ -133,9 +146,17 @@ def reflect(l, m, n, ux, uy, uz, mask=None):
 
 
 def radgrat(x, y, l, m, n, wave, dpermm, order, mask=None):
-    # argument order of the f2py signature: (x,y,l,m,n,wave,dpermm,order)
+    # f2py signature (x,y,l,m,n,wave,dpermm,order); the C entry takes wave before num
     num, dev = _check_cols((x, y, l, m, n), "pxf_radgrat")
     mp = _mask_ptr(mask, num, dev, "pxf_radgrat")
+    rec = fused.active()
+    if rec is not None and num:
+        tail = (float(wave), float(dpermm), float(order))
+        if rec.try_add("pxf_radgrat", (x, y, l, m, n), tail, mask):
+            return
+        rec.flush()
+        if rec.try_add("pxf_radgrat", (x, y, l, m, n), tail, mask):
+            return
     with torch.cuda.device(dev):
         rc = _lib.lib().pxf_radgrat(x.data_ptr(), y.data_ptr(), l.data_ptr(), m.data_ptr(), n.data_ptr(),
                                     float(wave), num, float(dpermm), float(order), mp, _stream(dev))

@@ -21,6 +21,7 @@ import math
 import numpy as np
 import torch
 
+from . import _fused as fused
 from . import _lib, native
 from .native import transformationsf as tran
 
@@ -134,6 +135,7 @@ def steerX(rays, coords=None):
 def pointTo(rays, x0, y0, z0, reverse=-1.):
     """Direct all ray direction cosines toward (x0,y0,z0); reverse=1. points them away.
     The reference rebinds rays[4:7] to new arrays (transformations.py:96-99); so do we."""
+    fused.flush()
     x, y, z = rays[1:4]
     num, dev = native._check_cols((x, y, z), "pointTo")
     out = [torch.empty_like(x) for _ in range(3)]
@@ -178,6 +180,7 @@ def _ptr_array(tensors):
 def vignette(rays, ind=None):
     """Remove vignetted rays from memory; ind is array of "good" indices, all others are removed.
     Default: keep rays with l^2+m^2+n^2 > .1 (transformations.py:214-225).  Returns a NEW list."""
+    fused.flush()
     cols = list(rays[:10])
     num, dev = native._check_cols(cols, "vignette")
     h = _lib.lib()
@@ -275,6 +278,7 @@ def applyT(rays, coords, inverse=False):
     """Apply transformation matrix to raylist; only rotations to direction cosines and normals.
     inverse=True goes back to the global system.  Returns a NEW list sharing rays[0]
     (transformations.py:257-280)."""
+    fused.flush()
     i = 2 if inverse is True else 0
     cols = list(rays[1:10])
     num, dev = native._check_cols(cols, "applyT")
@@ -290,6 +294,7 @@ def applyT(rays, coords, inverse=False):
 
 def applyTPos(x, y, z, coords, inverse=False):
     """Apply transformation to list of points (transformations.py:282-289).  Returns a (3, N) tensor."""
+    fused.flush()
     i = 2 if inverse is True else 0
     num, dev = native._check_cols((x, y, z), "applyTPos")
     mpos, ppos = _m16(coords[i + 1])

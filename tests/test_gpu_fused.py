@@ -1,0 +1,153 @@
+"""GPU tests of the fused ray program (pxf_program_run / pyxfocus_amd.fused()): results must be
+BIT-IDENTICAL to issuing the same calls one launch at a time, for every fusable operation, with
+and without `ind`, including failed (sentinel) rays."""
+import numpy as np
+import pytest
+
+from oracle import cases
+from util import ALLCOLS, bits_equal
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev_rays(c):
+    return [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+
+
+def same(a, b):
+    for k, u, v in zip(ALLCOLS, a, b):
+        assert bits_equal(u.cpu().numpy(), v.cpu().numpy()).all(), "column " + k
+
+
+def chain(rays, tran, surf, nr=None):
+    tran.transform(rays, 0, 0, -(cases.Z0 + 2 * cases.LMIR), 0, 0, 0)
+    surf.wolterprimary(rays, cases.R0, cases.Z0, cases.PSI, nr=nr)
+    tran.reflect(rays)
+    surf.woltersecondary(rays, cases.R0, cases.Z0, cases.PSI)
+    tran.reflect(rays)
+    surf.flat(rays, nr=nr)
+
+
+@pytest.mark.parametrize("n", [1, 2, 1001, 500_000, 4_000_001])
+def test_fused_chain_equals_eager_and_golden(golden, n):
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(n)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    c = cases.annulus_rays(rng, n, rin, rout, 0.)
+    c["ux"][:] = rng.normal(size=n)          # the dropped transform-normal must not matter
+    a, b = dev_rays(c), dev_rays(c)
+    chain(a, tran, surf)
+    with pxf.fused() as rec:
+        chain(b, tran, surf)
+    assert rec.launches == 1 and rec.fused_ops == 6
+    same(a, b)
+    if n == 1001:
+        g = golden["chain_config2"]
+        r = [torch.from_numpy(g["in/" + k].copy()).cuda() for k in ALLCOLS]
+        with pxf.fused():
+            chain(r, tran, surf)
+        for k, t in zip(ALLCOLS, r):
+            assert bits_equal(t.cpu().numpy(), g["out/" + k]).all(), k
+
+
+def test_fused_opd_and_offaxis():
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(3)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    c = cases.annulus_rays(rng, 300_001, rin, rout, 0.)
+    c["l"][:] = 1e-3
+    c["n"][:] = -np.sqrt(1 - 1e-6)
+    a, b = dev_rays(c), dev_rays(c)
+    chain(a, tran, surf, nr=1.25)
+    with pxf.fused():
+        chain(b, tran, surf, nr=1.25)
+    same(a, b)
+
+
+def test_fused_every_op_with_and_without_ind():
+    """A long mixed program: frame moves (general rotation), conic incl. missed rays, grating with
+    scalar and per-ray wavelength, masked and unmasked -- eager vs fused."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(17)
+    n = 200_003
+    c = cases._randrays(rng, n, nsign=-1.)
+    c["l"] *= .1; c["m"] *= .1
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    c["z"] = rng.uniform(50, 150, n)
+    c["x"][:5] = 5e4                                   # conic misses -> in-band sentinel
+    m1 = rng.random(n) < .5
+    m2 = np.where(rng.random(n) < .3)[0]
+    wave = rng.uniform(1., 3., n)
+
+    def program(r):
+        tran.transform(r, 1., -2., 3., .01, -.02, .03)
+        surf.conic(r, 1000., -1.)
+        tran.reflect(r, ind=m1)
+        tran.itransform(r, .5, .5, -.5, 0., .1, 0., ind=m2)
+        surf.flat(r, ind=m1)
+        tran.radgrat(r, 160. / 11832., 1., 2.4)
+        tran.radgrat(r, 160. / 11832., -1., wave, ind=m1)
+        surf.conic(r, -2000., .5, nr=1.5)
+        tran.transform(r, 0, 0, 10., 0, 0, 0)
+        surf.flat(r, nr=1.)
+        tran.reflect(r)
+
+    a, b = dev_rays(c), dev_rays(c)
+    program(a)
+    with pxf.fused() as rec:
+        program(b)
+    assert rec.launches == 1 and rec.fused_ops == 11
+    same(a, b)
+
+
+def test_fused_flushes_around_unfusable_calls():
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.analyses as anal
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(5)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    c = cases.annulus_rays(rng, 100_000, rin, rout, 0.)
+    a, b = dev_rays(c), dev_rays(c)
+    chain(a, tran, surf)
+    ra = anal.rmsCentroid(a)
+    va = tran.vignette(a, ind=np.arange(0, 100_000, 3))
+    surf.flat(va)
+    with pxf.fused() as rec:
+        chain(b, tran, surf)
+        rb = anal.rmsCentroid(b)                   # reduction inside the block -> flush first
+        vb = tran.vignette(b, ind=np.arange(0, 100_000, 3))
+        surf.flat(vb)                              # a different bundle -> its own program
+    assert ra == rb
+    same(a, b)
+    same(va, vb)
+    assert rec.launches == 2
+    # an exception inside the block discards the pending program instead of running it
+    d = dev_rays(c)
+    with pytest.raises(RuntimeError):
+        with pxf.fused():
+            tran.transform(d, 0, 0, 1., 0, 0, 0)
+            raise RuntimeError("boom")
+    assert bits_equal(d[3].cpu().numpy(), c["z"]).all()
+
+
+def test_fused_more_ops_than_one_program_holds():
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(8)
+    c = cases._randrays(rng, 10_001)
+    a, b = dev_rays(c), dev_rays(c)
+    for i in range(75):
+        tran.transform(a, .1, 0, 0, 0, 0, 1e-3 * i)
+    with pxf.fused() as rec:
+        for i in range(75):
+            tran.transform(b, .1, 0, 0, 0, 0, 1e-3 * i)
+    assert rec.launches == 3 and rec.fused_ops == 75
+    same(a, b)

@@ -155,3 +155,39 @@ def test_bench_cli_and_chain_definition():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert sum(mod.BYTES[k] for k in mod.CHAIN) == 576
+
+
+def test_program_planner_liveness():
+    """pxf_program_plan (host only): load/store sets and dead-group elimination."""
+    from pyxfocus_amd import _fused as f
+
+    def mk(code, *a, mask=None):
+        o = f.PxfOp()
+        o.code = code
+        o.mask = mask
+        for i, v in enumerate(a):
+            o.a[i] = v
+        return o
+    X = lambda *cols: sum(1 << "opd x y z l m n ux uy uz".split().index(c) for c in cols)
+    pos, dirs, nrm = X("x", "y", "z"), X("l", "m", "n"), X("ux", "uy", "uz")
+    # two-bounce chain: the normal rotation of the leading transform is dead -> 6 loads, 9 stores
+    chain = [mk(8, 0, 0, 8600, 0, 0, 0), mk(5, 220, 8400, 1), mk(10), mk(7, 220, 8400, 1), mk(10), mk(1)]
+    assert f.plan(chain) == (pos | dirs, pos | dirs | nrm, 1)
+    # a lone transform moves all three groups
+    assert f.plan([mk(8, 1, 2, 3, .1, .2, .3)]) == (pos | dirs | nrm, pos | dirs | nrm, 0)
+    # reflect reads the normal but only stores the direction
+    assert f.plan([mk(10)]) == (dirs | nrm, dirs, 0)
+    # a MASKED flat must load what it conditionally overwrites (normals) and nothing is dead before it
+    assert f.plan([mk(8, 0, 0, 1, 0, 0, 0), mk(1, mask=1234)]) == (pos | dirs | nrm, pos | dirs | nrm, 0)
+    # conic may miss: position/normal conditionally written -> loaded
+    assert f.plan([mk(3, 1000., -1.)]) == (pos | dirs | nrm, pos | dirs | nrm, 0)
+    # OPD variants bring the opd column in
+    assert f.plan([mk(2, 1.5)]) == (X("opd") | pos | dirs, X("opd") | pos | nrm, 0)
+    # radgrat reads x,y only
+    assert f.plan([mk(11, 2.4, .01, 1.)]) == (X("x", "y") | dirs, dirs, 0)
+    # two transforms then flat: the first transform's normal AND the second's are dead
+    assert f.plan([mk(8, 0, 0, 1, 0, 0, 0), mk(9, 0, 0, 1, .1, 0, 0), mk(1)])[2] == 2
+    import pytest as _pt
+    from pyxfocus_amd import _lib
+    with _pt.raises(_lib.PxfError):
+        f.plan([mk(99)])
