@@ -58,9 +58,11 @@ def chain_step(rays, tran, surf, ev=None):
     mark(6)
 
 
-def cpu_baseline(target_seconds=12.0):
+def cpu_baseline(gpu_chain, target_seconds=12.0):
     """Reference Fortran (oracle/_ref, OpenMP build) -- or our C port if _ref did not travel --
-    timed on this box's host cores on a bounded sample of the same workload."""
+    timed on this box's host cores on a bounded sample of the same workload.  The first 1e5 rays of
+    the sample also go through the GPU path (`gpu_chain(cols, fused)`), and the two results are
+    compared: the checker's only other job in this file."""
     from oracle import api, cases
     # threads actually usable: the cgroup CPU quota (16 on a 1-GPU box), not the 256 visible cores;
     # must be in the environment BEFORE the OpenMP runtime initialises
@@ -94,10 +96,19 @@ def cpu_baseline(target_seconds=12.0):
         cases.chain_config2(be, c)
         spent += time.perf_counter() - t0
         reps += 1
+    chk = 100_000
+    want = {k: v[:chk] for k, v in c.items()}
+    parity = {"rays": chk, "checker": kind}
+    for tag, fused in (("", False), ("fused_", True)):
+        got = gpu_chain({k: v[:chk].copy() for k, v in src.items()}, fused)
+        err = np.sqrt(np.mean(sum((got[k] - want[k]) ** 2 for k in "xyz")))
+        parity[tag + "rms_pos_err_mm"] = float(err)
+        parity[tag + "bit_identical"] = bool(all(np.array_equal(got[k], want[k]) for k in cases.ALLCOLS))
     return {"value": n * reps / spent, "unit": "rays/s", "cores": cores, "kind": kind,
             "sample": "%d x %d rays, same config-2 chain, %s, %.1f s of CPU time" % (
                 reps, n, "PyXFocus Fortran compiled with flang -O2 -fopenmp (oracle/_ref)" if kind == "reference"
-                else "C restatement oracle/pxf_oracle.c -O2 -fopenmp", spent)}
+                else "C restatement oracle/pxf_oracle.c -O2 -fopenmp", spent),
+            "parity_vs_gpu": parity}
 
 
 def main():
@@ -144,30 +155,6 @@ def main():
     def fresh(i):
         # global ray index: rank r owns [r*N, (r+1)*N) of step i's bundle -> independent of n_gpus
         return sources.annulus(rin, rout, N, rng="philox", seed=1000 + i, first_index=rank * N)
-
-    # ---- parity spot check on this rank's first rays (outside the timed region) ------------
-    parity = None
-    if rank == 0:
-        from oracle import api, cases
-        port = api.load_port()
-        chk = min(N, 100_000)
-        r0_ = sources.annulus(rin, rout, chk, rng="philox", seed=999)
-        host = {k: v.cpu().numpy() for k, v in zip(cases.ALLCOLS, r0_)}
-        cases.chain_config2(port, host)
-        chain_step(r0_, tran, surf)
-        got = {k: v.cpu().numpy() for k, v in zip(cases.ALLCOLS, r0_)}
-        err = np.sqrt(np.mean(sum((got[k] - host[k]) ** 2 for k in "xyz")))
-        bit = all(np.array_equal(got[k], host[k]) for k in cases.ALLCOLS)
-        parity = {"rays": chk, "rms_pos_err_mm_vs_oracle": float(err), "bit_identical": bool(bit)}
-        if not args.no_fused:
-            import pyxfocus_amd as pxf
-            r1_ = sources.annulus(rin, rout, chk, rng="philox", seed=999)
-            with pxf.fused():
-                chain_step(r1_, tran, surf)
-            parity["fused_bit_identical"] = bool(all(np.array_equal(v.cpu().numpy(), host[k])
-                                                     for k, v in zip(cases.ALLCOLS, r1_)))
-            del r1_
-        del r0_
 
     # ---- warm-up -------------------------------------------------------------------------
     for i in range(W):
@@ -294,11 +281,19 @@ def main():
                           "bundles_pregenerated": pool, "bundles_regenerated_in_timed_region": regen},
                "roofline": roofline,
                "chain_GBps": chain_gbps, "chain_frac_of_hbm_peak": chain_gbps / HBM_PEAK_GBS,
-               "kernels": kern, "focal_rms_centroid_mm": rms, "parity": parity, "focal_gather": gather,
+               "kernels": kern, "focal_rms_centroid_mm": rms, "focal_gather": gather,
                "fused": fused}
         if n_gpus == 1 and not args.no_cpu_baseline:
+            def gpu_chain(cols, use_fused):
+                import contextlib
+                import pyxfocus_amd as pxf
+                order = "opd x y z l m n ux uy uz".split()
+                r = [torch.from_numpy(cols[k]).to(dev) for k in order]
+                with (pxf.fused() if use_fused else contextlib.nullcontext()):
+                    chain_step(r, tran, surf)
+                return {k: v.cpu().numpy() for k, v in zip(order, r)}
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(gpu_chain)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)

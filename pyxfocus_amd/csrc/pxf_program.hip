@@ -11,6 +11,8 @@
 // kernel is a wave-uniform interpreter: `switch (op.code)` is a scalar branch (no divergence),
 // and each case is the SAME Op::apply the stand-alone kernels instantiate, so the two paths are
 // bit-identical by construction.  Two rays per thread, 16-byte accesses, NT policy as elsewhere.
+#include <stdlib.h>
+
 #include "pxf_ops_surfaces.h"
 #include "pxf_ops_transforms.h"
 
@@ -40,7 +42,8 @@ __device__ __forceinline__ void run_op(const OP &o, Ray (&r)[V], const bool (&se
     o.template apply<V>(r, sel, wm);
 }
 
-template <int V, bool NT>
+// ANYMASK=false instantiations carry no per-op mask code (no saved copy of the ray -> fewer VGPRs)
+template <int V, bool NT, bool ANYMASK>
 __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, 
         for (int i = 0; i < pg.nops; i++) {
             const ProgOp &o = pg.op[i];
             bool sel[V];
-            Ray keep[V];
-            const bool masked = o.mask != nullptr;
+            Ray keep[ANYMASK ? V : 1];
+            const bool masked = ANYMASK && o.mask != nullptr;
             if (masked) {
 #pragma unroll
                 for (int k = 0; k < V; k++) {
@@ -291,17 +294,31 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
         if (pg.op[i].aux && ((uintptr_t)pg.op[i].aux & 15)) aligned = false;
     hipStream_t s = (hipStream_t)stream;
     const bool nt = use_nt(num);
-    const int64_t nvec2 = aligned ? num / 2 : 0;
-    if (nvec2 > 0) {
-        if (nt)
-            hipLaunchKernelGGL((program_kernel<2, true>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);
-        else
-            hipLaunchKernelGGL((program_kernel<2, false>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);
+    bool anymask = false;
+    for (int i = 0; i < pg.nops; i++) anymask |= pg.op[i].mask != nullptr;
+    static int force_v = -1;
+    if (force_v < 0) {
+        const char *e = getenv("PXF_PROGRAM_V");
+        force_v = e ? atoi(e) : 0;
     }
+    const int64_t nvec2 = (aligned && force_v != 1) ? num / 2 : 0;
+#define PXF_PLAUNCH(V, T, A, FIRST, NVEC)                                                                   \
+    hipLaunchKernelGGL((program_kernel<V, T, A>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg)
+#define PXF_PLAUNCH_V(V, FIRST, NVEC)                      \
+    do {                                                   \
+        if (anymask) {                                     \
+            if (nt) PXF_PLAUNCH(V, true, true, FIRST, NVEC);    \
+            else PXF_PLAUNCH(V, false, true, FIRST, NVEC);      \
+        } else {                                           \
+            if (nt) PXF_PLAUNCH(V, true, false, FIRST, NVEC);   \
+            else PXF_PLAUNCH(V, false, false, FIRST, NVEC);     \
+        }                                                  \
+    } while (0)
+    if (nvec2 > 0) PXF_PLAUNCH_V(2, (int64_t)0, nvec2);
     const int64_t done = nvec2 * 2;
-    if (done < num)
-        hipLaunchKernelGGL((program_kernel<1, false>), dim3(grid_for(num - done)), dim3(kBlock), 0, s, c, done,
-                           num - done, pg);
+    if (done < num) PXF_PLAUNCH_V(1, done, num - done);
+#undef PXF_PLAUNCH_V
+#undef PXF_PLAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }

@@ -179,3 +179,70 @@ def test_transform_roundtrip_property():
     native.transformationsf.itransform(*cols, *p)
     for a, b in zip(cols, orig):
         assert float((a - b).abs().max()) < 5e-15
+
+
+def test_full_size_1e9_rays_properties(port):
+    """BASELINE config 3 at its full size: 1e9 rays on one GPU (80 GB bundle), one launch per call.
+    Size-independent properties + the first 1e5 rays against the oracle bit for bit (the device
+    source is keyed on the global ray index, so a 1e5-ray bundle with the same seed IS the head of
+    the 1e9-ray bundle)."""
+    import math
+    import pyxfocus_amd.sources as sources
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from pyxfocus_amd import conicsolve as con
+    free, total = torch.cuda.mem_get_info()
+    n = 1_000_000_000
+    if free < 100e9:
+        pytest.skip("needs ~90 GB of free HBM")
+    r0, z0, L = cases.R0, cases.Z0, cases.LMIR
+    rin, rout = float(con.primrad(z0, r0, z0)), float(con.primrad(z0 + L, r0, z0))
+    zg, g = 8000., 1.5 * math.pi / 180
+
+    def trace(rays):
+        tran.transform(rays, 0, 0, -(z0 + 2 * L), 0, 0, 0)
+        surf.wolterprimary(rays, r0, z0)
+        tran.reflect(rays)
+        surf.woltersecondary(rays, r0, z0)
+        tran.reflect(rays)
+        tran.transform(rays, 0, -zg * math.sin(g), 0, math.pi / 2 - g, 0, 0)
+        surf.flat(rays)
+        tran.reflect(rays)
+        tran.radgrat(rays, 160. / zg, 1., 2.4)
+        tran.itransform(rays, 0, -zg * math.sin(g), 0, math.pi / 2 - g, 0, 0)
+        surf.flat(rays)
+
+    rays = sources.subannulus(rin, rout, 0.5, n, zhat=-1., rng="philox", seed=77)
+    assert rays[0].shape[0] == n
+    trace(rays)
+    head = [r[:100_000].cpu().numpy() for r in rays]
+    tail = [r[-100_000:].cpu().numpy() for r in rays]
+    # properties over ALL 1e9 rays
+    assert bool((rays[3] == 0).all())                                   # on the focal plane
+    mag = rays[4] * rays[4] + rays[5] * rays[5] + rays[6] * rays[6]
+    assert float((mag - 1).abs().max()) < 1e-12                         # unit direction cosines
+    assert bool(torch.isfinite(rays[1]).all()) and bool(torch.isfinite(rays[6]).all())
+    assert bool((rays[9] == 1).all()) and bool((rays[7] == 0).all())    # flat's normal
+    del rays, mag
+    torch.cuda.empty_cache()
+    # the same first / last 1e5 global indices as small bundles, through the oracle
+    for first, got in ((0, head), (n - 100_000, tail)):
+        small = sources.subannulus(rin, rout, 0.5, 100_000, zhat=-1., rng="philox", seed=77, first_index=first)
+        c = {k: v.cpu().numpy() for k, v in zip(ALLCOLS, small)}
+        a = [c[k] for k in ALLCOLS[1:]]
+        T = port.transformationsf
+        T.transform(*a, 0., 0., z0 + 2 * L, 0., 0., 0.)
+        port.woltsurf.wolterprimary(*a, r0, z0, 1.)
+        T.reflect(*a[3:])
+        port.woltsurf.woltersecondary(*a, r0, z0, 1.)
+        T.reflect(*a[3:])
+        T.transform(*a, 0., zg * math.sin(g), 0., -(math.pi / 2 - g), 0., 0.)
+        port.surfacesf.flat(*a)
+        T.reflect(*a[3:])
+        xs, ys, ls, ms, ns = (c[k] for k in ("x", "y", "l", "m", "n"))
+        T.radgrat(xs, ys, ls, ms, ns, 2.4, 160. / zg, 1.)
+        T.itransform(*a, 0., zg * math.sin(g), 0., -(math.pi / 2 - g), 0., 0.)
+        port.surfacesf.flat(*a)
+        for k, u in zip(ALLCOLS, got):
+            # everything up to radgrat is bit-identical; radgrat is 1e-14-level, then propagated ~8 m
+            assert np.abs(u - c[k]).max() < 5e-10, (k, np.abs(u - c[k]).max())

@@ -9,7 +9,7 @@ import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('value %.4g rays/s  ms/step %.3f  chain %.0f GB/s' % (j['value'], j['ms_per_step'], j['chain_GBps']))
 print('  '+'  '.join('%s %.3f(%.0f)' % (k['kernel'][:6], k['avg_ms'], k['GBps']) for k in j['kernels']))
-print('  parity', j['parity'])
+
 " || exit 1
   done
 done

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Measure BASELINE configs 3 and 4 on one MI355X (not the headline bench line; see bench.py).
+
+config3: two-bounce Wolter-I (sub-aperture) + one radial grating, SURVEY 8d:
+         config-2 chain ... reflect, then transform -> flat -> reflect -> radgrat -> itransform -> flat
+         (576 - 96 + 616 = 1096+96 = 1192 algorithmic B/ray with one launch per call)
+config4: 36-term Zernike sag surface (rad 50): zernsurf -> reflect -> flat (264 B/ray); fp64-VALU-bound.
+
+Per-launch HIP-event timing; eager (one launch per call) and fused (one launch) variants.
+Prints one JSON object per config.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import pyxfocus_amd as pxf  # noqa: E402
+import pyxfocus_amd.analyses as anal  # noqa: E402
+import pyxfocus_amd.sources as sources  # noqa: E402
+import pyxfocus_amd.surfaces as surf  # noqa: E402
+import pyxfocus_amd.transformations as tran  # noqa: E402
+from pyxfocus_amd import conicsolve as con  # noqa: E402
+
+R0, Z0, PSI, L = 220., 8400., 1., 100.
+GRAZE, ZG = 1.5 * math.pi / 180, 8000.
+
+
+class Timer:
+    def __init__(self):
+        self.rows = []
+
+    def run(self, name, nbytes, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.rows.append((name, nbytes, a, b))
+
+    def table(self, n):
+        out = []
+        for name, nbytes, a, b in self.rows:
+            ms = a.elapsed_time(b)
+            out.append({"kernel": name, "ms": ms, "bytes_per_ray": nbytes,
+                        "GBps": nbytes * n / (ms * 1e-3) / 1e9 if nbytes else None})
+        return out
+
+
+def config3_steps(rays, t=None):
+    run = t.run if t else (lambda name, nb, fn: fn())
+    run("transform", 144, lambda: tran.transform(rays, 0, 0, -(Z0 + 2 * L), 0, 0, 0))
+    run("wolterprimary", 96, lambda: surf.wolterprimary(rays, R0, Z0, PSI))
+    run("reflect", 72, lambda: tran.reflect(rays))
+    run("woltersecondary", 96, lambda: surf.woltersecondary(rays, R0, Z0, PSI))
+    run("reflect", 72, lambda: tran.reflect(rays))
+    run("flat", 96, lambda: surf.flat(rays))
+    # grating stage (frame: origin = focus = grating hub)
+    ty, rx = -ZG * math.sin(GRAZE), math.pi / 2 - GRAZE
+    run("transform(g)", 144, lambda: tran.transform(rays, 0, ty, 0, rx, 0, 0))
+    run("flat(g)", 96, lambda: surf.flat(rays))
+    run("reflect(g)", 72, lambda: tran.reflect(rays))
+    run("radgrat", 64, lambda: tran.radgrat(rays, 160. / ZG, 1., 2.4))
+    run("itransform(g)", 144, lambda: tran.itransform(rays, 0, ty, 0, rx, 0, 0))
+    run("flat(focal)", 96, lambda: surf.flat(rays))
+
+
+def config3(n, reps):
+    rin, rout = float(con.primrad(Z0, R0, Z0)), float(con.primrad(Z0 + L, R0, Z0))
+    res = {"config": 3, "rays": n, "algorithmic_bytes_per_ray": 1192}
+    best = None
+    for r in range(reps + 1):
+        rays = sources.subannulus(rin, rout, 0.5, n, zhat=-1., rng="philox", seed=30 + r)
+        t = Timer()
+        config3_steps(rays, t)
+        torch.cuda.synchronize()
+        tab = t.table(n)
+        tot = sum(k["ms"] for k in tab)
+        if r > 0 and (best is None or tot < best[0]):
+            best = (tot, tab)
+        if r == reps:
+            res["valid_fraction"] = float(torch.isfinite(rays[6]).double().mean())
+            res["focal_rms_x_mm"], res["focal_rms_y_mm"] = anal.rmsX(rays), anal.rmsY(rays)
+            chk = [c.clone() for c in rays]
+        del rays
+    res["eager"] = {"ms": best[0], "rays_per_s": n / (best[0] * 1e-3), "GBps": 1192 * n / (best[0] * 1e-3) / 1e9,
+                    "kernels": best[1]}
+    fbest = None
+    for r in range(reps + 1):
+        rays = sources.subannulus(rin, rout, 0.5, n, zhat=-1., rng="philox", seed=30 + reps if r == reps else 90 + r)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        with pxf.fused():
+            config3_steps(rays)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b)
+        if r > 0 and (fbest is None or ms < fbest):
+            fbest = ms
+        if r == reps:
+            res["fused_bit_identical_to_eager"] = bool(all(
+                torch.equal(torch.nan_to_num(u), torch.nan_to_num(v)) and torch.equal(u.isnan(), v.isnan())
+                for u, v in zip(rays, chk)))
+        del rays
+    res["fused"] = {"ms": fbest, "rays_per_s": n / (fbest * 1e-3)}
+    return res
+
+
+def config4(n, reps, nterms=36):
+    rng = np.random.default_rng(4)
+    coeff = rng.normal(0., 1e-3, nterms)
+    coeff[0] = 0.
+    ro, ao = surf.zmodes(nterms)
+    res = {"config": 4, "rays": n, "terms": nterms, "nmax": int(ro.max()), "algorithmic_bytes_per_ray": 264}
+    best = None
+    for r in range(reps + 1):
+        rays = sources.circularbeam(50., n, rng="philox", seed=40 + r)
+        rays[3].fill_(10.)
+        rays[4].fill_(0.01)
+        rays[6].fill_(-math.sqrt(1 - 1e-4))
+        t = Timer()
+        t.run("zernsurf", 96, lambda: surf.zernsurf(rays, coeff, 50., rorder=ro, aorder=ao))
+        t.run("reflect", 72, lambda: tran.reflect(rays))
+        t.run("flat", 96, lambda: surf.flat(rays))
+        torch.cuda.synchronize()
+        tab = t.table(n)
+        tot = sum(k["ms"] for k in tab)
+        if r > 0 and (best is None or tot < best[0]):
+            best = (tot, tab)
+        if r == reps:
+            res["valid_fraction"] = float(torch.isfinite(rays[1]).double().mean())
+        del rays
+    z = best[1][0]
+    res["eager"] = {"ms": best[0], "rays_per_s": n / (best[0] * 1e-3), "kernels": best[1]}
+    res["zernsurf_rays_per_s"] = n / (z["ms"] * 1e-3)
+    res["zernsurf_hbm_frac_of_8TBps"] = z["GBps"] / 8000.
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=float, default=1e8)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--configs", default="3,4")
+    args = ap.parse_args()
+    n = int(args.rays)
+    torch.cuda.set_device(0)
+    for c in args.configs.split(","):
+        res = config3(n, args.reps) if c == "3" else config4(n, args.reps)
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,8 @@ from collections import defaultdict
 
 src, tag, out_dir = sys.argv[1], sys.argv[2], sys.argv[3]
 ALG = {"TransformOp": 144, "WolterPrimaryOp": 96, "WolterSecondaryOp": 96, "ReflectOp": 72, "FlatOp": 96,
-       "RadgratOp": 64, "ConicOp": 96, "ZernOpSel": 96, "source_kernel": 80}
+       "RadgratOp": 64, "ConicOp": 96, "ZernOpSel": 96, "source_kernel": 80,
+       "program_kernel": 120}  # program_kernel: the config-2 chain fused (6 columns read, 9 written)
 
 
 def short(name):
