@@ -195,6 +195,20 @@ int pxf_moments(const double *x, const double *y, const double *l, const double 
 int pxf_central_moments(const double *x, const double *y, const double *w, int64_t num, double cx,
                         double cy, double *out_dev, void *workspace, pxf_stream_t stream);
 
+/* analyses.rho (analyses.py:60-71): out[i] = sqrt((x-cx)^2 + (y-cy)^2) */
+int pxf_rho(const double *x, const double *y, double cx, double cy, double *out, int64_t num,
+            pxf_stream_t stream);
+/* analyses.indAngle / grazeAngle (analyses.py:164-187): out[i] = acos(d.u)  (graze!=0: pi/2 - acos(d.u)) */
+int pxf_indangle(const double *l, const double *m, const double *n, const double *ux, const double *uy,
+                 const double *uz, double *out, int64_t num, int32_t graze, pxf_stream_t stream);
+/* Order statistics without sorting (radix select on the device): out_dev[j] = the k[j]-th smallest
+ * (0-based) element of v, for nk <= 2 ranks given as a HOST array; NaN anywhere -> NaN (np.median).
+ * analyses.hpd (analyses.py:88-97) = 2 * mean of the two middle radii.  `workspace`:
+ * pxf_select_workspace_bytes() bytes of device memory. */
+size_t pxf_select_workspace_bytes(void);
+int pxf_kth_values(const double *v, int64_t num, const int64_t *k, int32_t nk, double *out_dev,
+                   void *workspace, pxf_stream_t stream);
+
 /* ---- sources.py on the device ------------------------------------------------------------------ */
 
 /* Counter-based Philox4x32-10 keyed on (seed, first_index + i): the bundle is a pure function of

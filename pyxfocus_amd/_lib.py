@@ -53,12 +53,17 @@ _SIGS = {
     "pxf_reduce_workspace_bytes": [],
     "pxf_moments": [_P] * 6 + [_i64, _P, _P, _P],
     "pxf_central_moments": [_P] * 3 + [_i64, _d, _d, _P, _P, _P],
+    "pxf_rho": [_P, _P, _d, _d, _P, _i64, _P],
+    "pxf_indangle": [_P] * 7 + [_i64, _i32, _P],
+    "pxf_select_workspace_bytes": [],
+    "pxf_kth_values": [_P, _i64, C.POINTER(C.c_int64), _i32, _P, _P, _P],
     "pxf_source": [_i32, _PP, _i64, _d, _d, _d, _d, _u64, _u64, _P],
     "pxf_program_run": [_P, _i32, _PP, _i64, _P],
     "pxf_program_plan": [_P, _i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)],
 }
 _RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,
-            "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t}
+            "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t,
+            "pxf_select_workspace_bytes": C.c_size_t}
 
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -107,17 +107,39 @@ def rho(rays, weights=None, cent=False):
     """Distance from the centroid (cent=True) or the origin for all rays (analyses.py:60-71)."""
     fused.flush()
     x, y = rays[1:3]
-    cx, cy = centroid(rays, weights=weights) if cent is True else (0, 0)
-    return torch.sqrt((x - cx) ** 2 + (y - cy) ** 2)
+    num, dev = native._check_cols((x, y), "rho")
+    cx, cy = centroid(rays, weights=weights) if cent is True else (0., 0.)
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_rho(x.data_ptr(), y.data_ptr(), float(cx), float(cy), out.data_ptr(), num,
+                                native._stream(dev))
+    _lib.check(rc, "pxf_rho")
+    return out
 
 
 def rhocdf(rays, weights=None, cent=True):
-    """Radial CDF of the ray distribution (analyses.py:73-86)."""
+    """Radial CDF of the ray distribution (analyses.py:73-86).  (argsort + cumsum on the device
+    via torch: the one analysis here that genuinely needs a full sort.)"""
     r = rho(rays, weights=weights, cent=cent)
     w = torch.ones_like(r) if weights is None else _weights(weights, r.shape[0], r.device)
     r, ind = torch.sort(r, stable=True)
     cdf = torch.cumsum(w[ind], 0)
     return r, cdf / cdf.max()
+
+
+def _kth(v, ranks):
+    """Order statistics of a device column by radix select (no sort); returns Python floats."""
+    num, dev = native._check_cols((v,), "kth_values")
+    h = _lib.lib()
+    ws = torch.empty(h.pxf_select_workspace_bytes(), dtype=torch.uint8, device=dev)
+    out = torch.empty(len(ranks), dtype=torch.float64, device=dev)
+    import ctypes as C
+    kk = (C.c_int64 * len(ranks))(*[int(k) for k in ranks])
+    with torch.cuda.device(dev):
+        rc = h.pxf_kth_values(v.data_ptr(), num, kk, len(ranks), out.data_ptr(), ws.data_ptr(),
+                              native._stream(dev))
+    _lib.check(rc, "pxf_kth_values")
+    return out.tolist()
 
 
 def hpd(rays, weights=None, cent=True):
@@ -130,9 +152,8 @@ def hpd(rays, weights=None, cent=True):
     n = r.shape[0]
     if n == 0:
         return float("nan")
-    lo = torch.kthvalue(r, (n - 1) // 2 + 1).values      # np.median: mean of the two middle values
-    hi = torch.kthvalue(r, n // 2 + 1).values
-    return float((lo + hi) * .5) * 2.
+    lo, hi = _kth(r, [(n - 1) // 2, n // 2])        # np.median: mean of the two middle values
+    return (lo + hi) * .5 * 2.
 
 
 def analyticImagePlane(rays, weights=None, group=None):
@@ -164,16 +185,27 @@ def analyticXPlane(rays, weights=None, group=None):
     return -bx / ax
 
 
-def indAngle(rays, ind=None, normal=None):
-    """Incidence angle of the rays with the current (or a given) surface normal (analyses.py:164-182)."""
+def indAngle(rays, ind=None, normal=None, _graze=0):
+    """Incidence angle of the rays with either the current or a specified surface normal
+    (analyses.py:164-182).  Returns a device tensor (of the `ind`-selected rays if ind is given)."""
     fused.flush()
-    sel = slice(None) if ind is None else ind
-    l, m, n = rays[4][sel], rays[5][sel], rays[6][sel]
-    if normal is None:
-        return torch.arccos(l * rays[7][sel] + m * rays[8][sel] + n * rays[9][sel])
-    return torch.arccos(normal[0] * l + normal[1] * m + normal[2] * n)
+    l, m, n, ux, uy, uz = rays[4:10]
+    num, dev = native._check_cols((l, m, n, ux, uy, uz), "indAngle")
+    if normal is not None:
+        ux, uy, uz = [torch.full_like(l, float(v)) for v in normal]
+    out = torch.empty_like(l)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_indangle(l.data_ptr(), m.data_ptr(), n.data_ptr(), ux.data_ptr(), uy.data_ptr(),
+                                     uz.data_ptr(), out.data_ptr(), num, _graze, native._stream(dev))
+    _lib.check(rc, "pxf_indangle")
+    if ind is None:
+        return out
+    if isinstance(ind, tuple):
+        ind = ind[0]
+    sel = ind if isinstance(ind, torch.Tensor) else torch.as_tensor(np.asarray(ind))
+    return out[sel.to(dev)]
 
 
 def grazeAngle(rays, ind=None):
     """Graze angle of the rays with the current surface normal (analyses.py:184-187)."""
-    return math.pi / 2 - indAngle(rays, ind=ind)
+    return indAngle(rays, ind=ind, _graze=1)

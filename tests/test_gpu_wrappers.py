@@ -324,3 +324,44 @@ def test_cpu_tensors_rejected_loudly():
     rays = sources.circularbeam(1., 8, device="cpu")
     with pytest.raises(TypeError):
         surf.flat(rays)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 64, 1001, 4096, 1_000_001, 20_000_000])
+def test_hpd_radix_select_matches_np_median(n):
+    """analyses.hpd = 2*median(rho) via on-device radix select (no sort): exact vs np.median for odd
+    and even counts, clustered values (a focal spot: all radii share exponent and leading bits),
+    duplicates, and NaN propagation."""
+    import pyxfocus_amd.analyses as anal
+    rng = np.random.default_rng(n)
+    for kind in ("spot", "wide", "dups"):
+        if kind == "spot":
+            x, y = rng.normal(0, 7e-6, n), rng.normal(0, 7e-6, n)
+        elif kind == "wide":
+            x, y = rng.normal(0, 1, n) * 10. ** rng.integers(-8, 8, n), rng.normal(0, 1, n)
+        else:
+            x, y = rng.integers(-3, 4, n).astype(float), rng.integers(-3, 4, n).astype(float)
+        rays = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(10)]
+        rays[1], rays[2] = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        cx, cy = anal.centroid(rays)
+        r = np.sqrt((x - cx) ** 2 + (y - cy) ** 2)
+        got = anal.hpd(rays)
+        assert got == np.median(r) * 2., (kind, n, got, np.median(r) * 2.)
+        assert np.array_equal(anal.rho(rays, cent=True).cpu().numpy(), r)
+    if n > 2:
+        rays[1][n // 3] = float("nan")
+        assert np.isnan(anal.hpd(rays))
+
+
+def test_graze_and_ind_angle():
+    import pyxfocus_amd.analyses as anal
+    from oracle import cases
+    rng = np.random.default_rng(3)
+    c = cases._randrays(rng, 100_003)
+    rays = [torch.from_numpy(c[k]).cuda() for k in ALLCOLS]
+    dot = c["l"] * c["ux"] + c["m"] * c["uy"] + c["n"] * c["uz"]
+    assert np.abs(anal.indAngle(rays).cpu().numpy() - np.arccos(dot)).max() < 1e-14
+    assert np.abs(anal.grazeAngle(rays).cpu().numpy() - (np.pi / 2 - np.arccos(dot))).max() < 1e-14
+    ind = rng.random(100_003) < .2
+    assert np.abs(anal.grazeAngle(rays, ind=ind).cpu().numpy() - (np.pi / 2 - np.arccos(dot[ind]))).max() < 1e-14
+    nrm = (0., 0., 1.)
+    assert np.abs(anal.indAngle(rays, normal=nrm).cpu().numpy() - np.arccos(c["n"])).max() < 1e-14
