@@ -70,6 +70,28 @@ int pxf_conicopd(double *opd, double *x, double *y, double *z, double *l, double
                  double *ux, double *uy, double *uz, int64_t num, double R, double K, double nr,
                  const uint8_t *mask, pxf_stream_t stream);
 
+/* tracesphere(x,...,uz,num,rad) / tracesphereOPD(opd,x,...,uz,num,rad,nr)   surfacesf.f95:57-98 / 101-148
+ * Sphere of radius rad about the origin, nearest root; a miss zeroes position and direction. */
+int pxf_tracesphere(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+                    double *uy, double *uz, int64_t num, double rad, const uint8_t *mask, pxf_stream_t stream);
+int pxf_tracesphereopd(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                       double *ux, double *uy, double *uz, int64_t num, double rad, double nr,
+                       const uint8_t *mask, pxf_stream_t stream);
+/* tracecyl / tracecylOPD   surfacesf.f95:153-196 / 199-246   (cylinder axis = y) */
+int pxf_tracecyl(double *x, double *y, double *z, double *l, double *m, double *n, double *ux, double *uy,
+                 double *uz, int64_t num, double rad, const uint8_t *mask, pxf_stream_t stream);
+int pxf_tracecylopd(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                    double *ux, double *uy, double *uz, int64_t num, double rad, double nr,
+                    const uint8_t *mask, pxf_stream_t stream);
+/* cylconic(x,...,uz,num,rad,k)   surfacesf.f95:251-296   (Newton; `rad` is a curvature) */
+int pxf_cylconic(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                 double *ux, double *uy, double *uz, int64_t num, double rad, double k,
+                 const uint8_t *mask, pxf_stream_t stream);
+/* paraxial / paraxialY (x,...,uz,num,F)   surfacesf.f95:423-439 / 443-459   (only x,y,l,m are touched) */
+int pxf_paraxial(const double *x, const double *y, double *l, double *m, int64_t num, double F,
+                 const uint8_t *mask, pxf_stream_t stream);
+int pxf_paraxialy(const double *y, double *m, int64_t num, double F, const uint8_t *mask, pxf_stream_t stream);
+
 /* ---- woltsurf.f95 ---------------------------------------------------------------------- */
 
 /* Van Speybroeck constants p,d,e from (r0,z0,psi), woltsurf.f95:18-23, evaluated on the host
@@ -91,6 +113,10 @@ int pxf_wolterprimaryopd(double *opd, double *x, double *y, double *z, const dou
 int pxf_woltersecondary(double *x, double *y, double *z, const double *l, const double *m,
                         const double *n, double *ux, double *uy, double *uz, int64_t num, double r0,
                         double z0, double psi, const uint8_t *mask, pxf_stream_t stream);
+
+/* spoCone(x,...,uz,num,R0,tg)   woltsurf.f95:591-638   (SPO cone; a miss zeroes the direction) */
+int pxf_spocone(double *x, double *y, double *z, double *l, double *m, double *n, double *ux, double *uy,
+                double *uz, int64_t num, double R0, double tg, const uint8_t *mask, pxf_stream_t stream);
 
 /* ---- zernsurf.f95 (+ zernset, specialFunctions.f95:142-232) ------------------------------- */
 
@@ -137,6 +163,16 @@ int pxf_radgrat(const double *x, const double *y, double *l, double *m, double *
 int pxf_radgratw(const double *x, const double *y, double *l, double *m, double *n,
                  const double *wave, int64_t num, double dpermm, double order, const uint8_t *mask,
                  pxf_stream_t stream);
+
+/* grat(x,y,l,m,n,num,d,order,wave)   transformationsf.f95:277-305   (linear grating, grooves along
+ * y; x,y are unused by the reference loop and not taken here).  Only the product order*wave
+ * enters: pass it as a scalar, or per ray as a device column (then the scalar is ignored). */
+int pxf_grat(double *l, double *m, double *n, int64_t num, double d, double order_times_wave,
+             const double *order_times_wave_col, const uint8_t *mask, pxf_stream_t stream);
+
+/* refract(l,m,n,ux,uy,uz,num,n1,n2)   transformationsf.f95:82-130 */
+int pxf_refract(double *l, double *m, double *n, double *ux, double *uy, double *uz, int64_t num, double n1,
+                double n2, const uint8_t *mask, pxf_stream_t stream);
 
 /* ---- transformations.py host-side helpers that touch every ray ----------------------------- */
 
@@ -251,6 +287,16 @@ int pxf_source(int32_t kind, double *const *cols, int64_t num, double p0, double
 #define PXF_OP_REFLECT 10
 #define PXF_OP_RADGRAT 11
 #define PXF_OP_RADGRATW 12
+#define PXF_OP_SPOCONE 13      /* a: R0, tg */
+#define PXF_OP_SPHERE 14       /* a: rad */
+#define PXF_OP_SPHEREOPD 15    /* a: rad, nr */
+#define PXF_OP_CYL 16          /* a: rad */
+#define PXF_OP_CYLOPD 17       /* a: rad, nr */
+#define PXF_OP_CYLCONIC 18     /* a: rad, k */
+#define PXF_OP_PARAXIAL 19     /* a: F */
+#define PXF_OP_PARAXIALY 20    /* a: F */
+#define PXF_OP_GRAT 21         /* a: d, order*wave ; aux (optional) = per-ray order*wave column */
+#define PXF_OP_REFRACT 22      /* a: n1, n2 */
 #define PXF_PROGRAM_MAX_OPS 32
 
 typedef struct pxf_op {

@@ -85,6 +85,15 @@ def load_port(omp=False):
     f_rg = sig("orc_radgrat", *[P] * 5, d, i64, d, d)
     f_rgw = sig("orc_radgratw", *[P] * 6, i64, d, d)
     f_par = sig("orc_wolter_params", d, d, d, P, P, P)
+    f_spo = sig("orc_spocone", *[P] * 9, i64, d, d)
+    f_grat = sig("orc_grat", *[P] * 5, i64, d, P, P)
+    f_sph = sig("orc_tracesphere", *[P] * 9, i64, d)
+    f_spho = sig("orc_tracesphereopd", *[P] * 10, i64, d, d)
+    f_cyl = sig("orc_tracecyl", *[P] * 9, i64, d)
+    f_cylo = sig("orc_tracecylopd", *[P] * 10, i64, d, d)
+    f_cc = sig("orc_cylconic", *[P] * 9, i64, d, d)
+    f_px = sig("orc_paraxial", *[P] * 4, i64, d, C.c_int)
+    f_rf = sig("orc_refract", *[P] * 6, i64, d, d)
 
     def flat(x, y, z, l, m, n, ux, uy, uz):
         p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
@@ -157,6 +166,48 @@ def load_port(omp=False):
         p, num = _cols(x, y, l, m, n, wave)
         f_rgw(*p, num, dpermm, order)
 
+    def spocone(x, y, z, l, m, n, ux, uy, uz, R0, tg):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_spo(*p, num, R0, tg)
+
+    def grat(x, y, l, m, n, d_, order, wave):
+        p, num = _cols(x, y, l, m, n)
+        ok, op_ = _f64in(np.broadcast_to(np.asarray(order, dtype=np.float64), (num,)))
+        wk, wp_ = _f64in(np.broadcast_to(np.asarray(wave, dtype=np.float64), (num,)))
+        f_grat(*p, num, d_, op_, wp_)
+
+    def tracesphere(x, y, z, l, m, n, ux, uy, uz, rad):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_sph(*p, num, rad)
+
+    def tracesphereopd(opd, x, y, z, l, m, n, ux, uy, uz, rad, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        f_spho(*p, num, rad, nr)
+
+    def tracecyl(x, y, z, l, m, n, ux, uy, uz, rad):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_cyl(*p, num, rad)
+
+    def tracecylopd(opd, x, y, z, l, m, n, ux, uy, uz, rad, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        f_cylo(*p, num, rad, nr)
+
+    def cylconic(x, y, z, l, m, n, ux, uy, uz, rad, k):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_cc(*p, num, rad, k)
+
+    def paraxial(x, y, z, l, m, n, ux, uy, uz, F):
+        p, num = _cols(x, y, l, m)
+        f_px(*p, num, F, 0)
+
+    def paraxialy(x, y, z, l, m, n, ux, uy, uz, F):
+        p, num = _cols(x, y, l, m)
+        f_px(*p, num, F, 1)
+
+    def refract(l, m, n, ux, uy, uz, n1, n2):
+        p, num = _cols(l, m, n, ux, uy, uz)
+        f_rf(*p, num, n1, n2)
+
     def wolter_params(r0, z0, psi=1.):
         o = [C.c_double() for _ in range(3)]
         f_par(r0, z0, psi, *[C.byref(v) for v in o])
@@ -164,12 +215,15 @@ def load_port(omp=False):
 
     return SimpleNamespace(
         kind="port", omp=omp,
-        surfacesf=SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd),
+        surfacesf=SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd,
+                                  tracesphere=tracesphere, tracesphereopd=tracesphereopd, tracecyl=tracecyl,
+                                  tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial,
+                                  paraxialy=paraxialy),
         woltsurf=SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
-                                 woltersecondary=woltersecondary),
+                                 woltersecondary=woltersecondary, spocone=spocone),
         zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
         transformationsf=SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
-                                         radgrat=radgrat, radgratw=radgratw),
+                                         radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract),
         wolter_params=wolter_params)
 
 
@@ -267,15 +321,38 @@ def load_ref(omp=False):
         p, num = _cols(x, y, l, m, n, wave)
         f_rgw(*p, num32(num), dref(dpermm), dref(order))
 
+    f_gr = fn("transformationsf", "grat")
+
+    def grat(x, y, l, m, n, d_, order, wave):
+        p, num = _cols(x, y, l, m, n)
+        ok, op_ = _f64in(np.array(np.broadcast_to(np.asarray(order, dtype=np.float64), (num,))))
+        wk, wp_ = _f64in(np.array(np.broadcast_to(np.asarray(wave, dtype=np.float64), (num,))))
+        f_gr(*p, num32(num), dref(d_), op_, wp_)        # grat(x,y,l,m,n,num,d,order,wave)
+
+    f_rfr = fn("transformationsf", "refract")
+
+    def refract(l, m, n, ux, uy, uz, n1, n2):
+        p, num = _cols(l, m, n, ux, uy, uz)
+        f_rfr(*p, num32(num), dref(n1), dref(n2))
+
     return SimpleNamespace(
         kind="reference", omp=omp,
         surfacesf=SimpleNamespace(flat=mk9("surfacesf", "flat", 0), flatopd=flatopd,
                                   conic=mk9("surfacesf", "conic", 2),
-                                  conicopd=mk10("surfacesf", "conicopd", 3)),
+                                  conicopd=mk10("surfacesf", "conicopd", 3),
+                                  tracesphere=mk9("surfacesf", "tracesphere", 1),
+                                  tracesphereopd=mk10("surfacesf", "tracesphereopd", 2),
+                                  tracecyl=mk9("surfacesf", "tracecyl", 1),
+                                  tracecylopd=mk10("surfacesf", "tracecylopd", 2),
+                                  cylconic=mk9("surfacesf", "cylconic", 2),
+                                  paraxial=mk9("surfacesf", "paraxial", 1),
+                                  paraxialy=mk9("surfacesf", "paraxialy", 1)),
         woltsurf=SimpleNamespace(wolterprimary=mk9("woltsurf", "wolterprimary", 3),
                                  wolterprimaryopd=mk10("woltsurf", "wolterprimaryopd", 4),
-                                 woltersecondary=mk9("woltsurf", "woltersecondary", 3)),
+                                 woltersecondary=mk9("woltsurf", "woltersecondary", 3),
+                                 spocone=mk9("woltsurf", "spocone", 2)),
         zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
         transformationsf=SimpleNamespace(transform=mk9("transformationsf", "transform", 6),
                                          itransform=mk9("transformationsf", "itransform", 6),
-                                         reflect=reflect, radgrat=radgrat, radgratw=radgratw))
+                                         reflect=reflect, radgrat=radgrat, radgratw=radgratw, grat=grat,
+                                         refract=refract))

@@ -32,6 +32,16 @@ SIG = {
     "transformationsf.reflect": "l m n ux uy uz",
     "transformationsf.radgrat": "x y l m n",
     "transformationsf.radgratw": "x y l m n",
+    "woltsurf.spocone": "x y z l m n ux uy uz",
+    "transformationsf.grat": "x y l m n",
+    "surfacesf.tracesphere": "x y z l m n ux uy uz",
+    "surfacesf.tracesphereopd": "opd x y z l m n ux uy uz",
+    "surfacesf.tracecyl": "x y z l m n ux uy uz",
+    "surfacesf.tracecylopd": "opd x y z l m n ux uy uz",
+    "surfacesf.cylconic": "x y z l m n ux uy uz",
+    "surfacesf.paraxial": "x y z l m n ux uy uz",
+    "surfacesf.paraxialy": "x y z l m n ux uy uz",
+    "transformationsf.refract": "l m n ux uy uz",
 }
 ALLCOLS = "opd x y z l m n ux uy uz".split()
 
@@ -216,6 +226,59 @@ def cases(num=2048, seed=1234):
     c["y"] *= rng.choice([-1., 1.], num)       # radgratW takes the sign of n from sign(y)
     wv = rng.uniform(1., 5., num)
     out.append(("radgratw_o1", "transformationsf.radgratw", c, (wv, 160. / hub, 1.)))
+
+    # ================= widening batch 1 (appended: earlier cases keep their random stream) ========
+    # ---- SPO cones (Arcus): rays above the intersection plane, travelling -z; some miss ------
+    for k, (R0s, F) in {"prim": (600., 12000.), "sec": (737.3, 12000.)}.items():
+        tg = (.25 if k == "prim" else .75) * math.atan((R0s + .605 / 2) / F)
+        c = annulus_rays(rng, num, R0s - .4, R0s + 1.2, 150. if k == "prim" else -20.)
+        c["l"] = rng.normal(0, 2e-4, num); c["m"] = rng.normal(0, 2e-4, num)
+        c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+        c["ux"] = rng.normal(size=num)
+        c["l"][0] = 0.; c["m"][0] = 1.; c["n"][0] = 0.; c["x"][0] = 5e4      # misses the cone: det < 0
+        out.append(("spocone_" + k, "woltsurf.spocone", c, (R0s, tg)))
+
+    # ---- linear grating: scalar-like (broadcast) and per-ray order/wave; evanescent -> zeros --
+    c = _randrays(rng, num)
+    c["l"] = rng.uniform(-.01, .01, num); c["m"] = rng.uniform(-.9999, -.9990, num)
+    c["n"] = np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2) * rng.choice([-1., 1.], num)
+    out.append(("grat_scalar", "transformationsf.grat", c, (160., np.full(num, 1.), np.full(num, 2.4))))
+    c = {kk: v.copy() for kk, v in c.items()}
+    out.append(("grat_arrays", "transformationsf.grat", c,
+                (200., rng.choice([-2., -1., 0., 1., 3.], num), rng.uniform(.5, 6., num))))
+
+    # ---- sphere / cylinder (centre at the origin); far rays miss -> zeroed ---------------------
+    for fn, tag in (("tracesphere", "sphere"), ("tracecyl", "cyl")):
+        c = _randrays(rng, num)
+        c["x"] = rng.uniform(-40, 40, num); c["y"] = rng.uniform(-40, 40, num); c["z"] = rng.uniform(150, 250, num)
+        c["l"] *= .2; c["m"] *= .2
+        c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+        c["x"][:3] = 500.                                # miss
+        out.append((tag, "surfacesf." + fn, c, (100.,)))
+        c2 = {kk: v.copy() for kk, v in c.items()}
+        out.append((tag + "opd", "surfacesf." + fn + "opd", c2, (100., 1.5)))
+
+    # ---- cylindrical conic y = c x^2 / (1 + sqrt(1-(1+k) c^2 x^2)), Newton -----------------------
+    c = _randrays(rng, num)
+    c["x"] = rng.uniform(-20, 20, num); c["y"] = rng.uniform(5, 10, num)
+    c["l"] = rng.uniform(-.05, .05, num); c["n"] = rng.uniform(-.05, .05, num)
+    c["m"] = -np.sqrt(1 - c["l"] ** 2 - c["n"] ** 2)
+    out.append(("cylconic", "surfacesf.cylconic", c, (1. / 500., -1.)))
+    c2 = {kk: v.copy() for kk, v in c.items()}
+    out.append(("cylconic_k05", "surfacesf.cylconic", c2, (-1. / 800., .5)))
+
+    # ---- paraxial lenses ----------------------------------------------------------------------
+    out.append(("paraxial", "surfacesf.paraxial", _randrays(rng, num), (250.,)))
+    out.append(("paraxialy", "surfacesf.paraxialy", _randrays(rng, num), (-75.5,)))
+
+    # ---- refraction: normals on both sides, one exactly-normal ray (dot == 1 -> untouched) -----
+    c = _randrays(rng, num)
+    c["ux"], c["uy"], c["uz"] = _unit(rng, num, spread=.2)
+    c["l"][0], c["m"][0], c["n"][0] = 0., 0., 1.
+    c["ux"][0], c["uy"][0], c["uz"][0] = 0., 0., 1.
+    out.append(("refract_in", "transformationsf.refract", c, (1., 1.5)))
+    c2 = {kk: v.copy() for kk, v in c.items()}
+    out.append(("refract_out", "transformationsf.refract", c2, (1.5, 1.)))   # incl. total internal reflection -> NaN
     return out
 
 

@@ -514,3 +514,214 @@ void orc_radgratw(const double *x, const double *y, double *l, double *m, double
 {
     radgrat_core(x, y, l, m, n, wave, 0., num, dpermm, order);
 }
+
+/* ==================================================================================== */
+/* Widening batch 1: SPO cones, linear grating, sphere, cylinder,
+ * cylindrical conic, paraxial lenses, refraction.                                         */
+
+/* woltsurf.f95:591-638 */
+void orc_spocone(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+                 double *uy, double *uz, int64_t num, double R0, double tg)
+{
+    const double sl = tan(tg), ctg = cos(tg), stg = sin(tg);
+#pragma omp parallel for
+    for (int64_t i = 0; i < num; i++) {
+        double A = n[i] * n[i] * (sl * sl) - m[i] * m[i] - l[i] * l[i];
+        double B = 2 * n[i] * sl * R0 + 2 * z[i] * (sl * sl) * n[i] - 2 * x[i] * l[i] - 2 * y[i] * m[i];
+        double C = R0 * R0 + 2 * sl * R0 * z[i] + z[i] * z[i] * (sl * sl) - x[i] * x[i] - y[i] * y[i];
+        double det = B * B - 4 * A * C;
+        if (det >= 0) {
+            double t1 = (-B + sqrt(det)) / (2 * A);
+            double t2 = (-B - sqrt(det)) / (2 * A);
+            if (fabs(t2) < fabs(t1)) t1 = t2;
+            x[i] = x[i] + t1 * l[i];
+            y[i] = y[i] + t1 * m[i];
+            z[i] = z[i] + t1 * n[i];
+            double rr = sqrt(x[i] * x[i] + y[i] * y[i]);
+            ux[i] = -x[i] / rr * ctg;
+            uy[i] = -y[i] / rr * ctg;
+            uz[i] = stg;
+        } else {
+            l[i] = 0.;
+            m[i] = 0.;
+            n[i] = 0.;
+        }
+    }
+}
+
+/* transformationsf.f95:277-305; order/wave are per-ray arrays in the Fortran signature */
+void orc_grat(const double *x, const double *y, double *l, double *m, double *n, int64_t num, double d,
+              const double *order, const double *wave)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double sn = n[i] / fabs(n[i]);
+        l[i] = l[i] - order[i] * wave[i] / d;
+        n[i] = sn * sqrt(1 - l[i] * l[i] - m[i] * m[i]);
+        if ((l[i] * l[i] + m[i] * m[i]) > 1) {
+            l[i] = 0.;
+            m[i] = 0.;
+            n[i] = 0.;
+        }
+    }
+}
+
+/* surfacesf.f95:57-98 (opd==NULL) and :101-148 */
+static void sphere_core(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                        double *ux, double *uy, double *uz, int64_t num, double rad, double nr)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double dotol = l[i] * x[i] + m[i] * y[i] + n[i] * z[i];
+        double mago = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
+        double determinant = dotol * dotol - mago + rad * rad;
+        if (determinant < 0) {
+            x[i] = y[i] = z[i] = 0.;
+            l[i] = m[i] = n[i] = 0.;
+        } else {
+            double d1 = -dotol + sqrt(determinant);
+            double d2 = -dotol - sqrt(determinant);
+            if (fabs(d2) < fabs(d1)) d1 = d2;
+            x[i] = x[i] + d1 * l[i];
+            y[i] = y[i] + d1 * m[i];
+            z[i] = z[i] + d1 * n[i];
+            if (opd) opd[i] = opd[i] + d1 * nr;
+        }
+        mago = sqrt(x[i] * x[i] + y[i] * y[i] + z[i] * z[i]);
+        ux[i] = x[i] / mago;
+        uy[i] = y[i] / mago;
+        uz[i] = z[i] / mago;
+    }
+}
+
+void orc_tracesphere(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+                     double *uy, double *uz, int64_t num, double rad)
+{
+    sphere_core(NULL, x, y, z, l, m, n, ux, uy, uz, num, rad, 0.);
+}
+
+void orc_tracesphereopd(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                        double *ux, double *uy, double *uz, int64_t num, double rad, double nr)
+{
+    sphere_core(opd, x, y, z, l, m, n, ux, uy, uz, num, rad, nr);
+}
+
+/* surfacesf.f95:153-196 (opd==NULL) and :199-246; cylinder axis = y */
+static void cyl_core(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                     double *ux, double *uy, double *uz, int64_t num, double rad, double nr)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double a = l[i] * l[i] + n[i] * n[i];
+        double b = 2 * (x[i] * l[i] + z[i] * n[i]);
+        double c = x[i] * x[i] + z[i] * z[i] - rad * rad;
+        double det = b * b - 4 * a * c;
+        if (det < 0) {
+            x[i] = y[i] = z[i] = 0.;
+            l[i] = m[i] = n[i] = 0.;
+        } else {
+            double d1 = (-b + sqrt(det)) / 2 / a;
+            double d2 = (-b - sqrt(det)) / 2 / a;
+            if (fabs(d2) < fabs(d1)) d1 = d2;
+            x[i] = x[i] + l[i] * d1;
+            y[i] = y[i] + m[i] * d1;
+            z[i] = z[i] + n[i] * d1;
+            if (opd) opd[i] = opd[i] + d1 * nr;
+        }
+        double mag = sqrt(x[i] * x[i] + z[i] * z[i]);
+        ux[i] = x[i] / mag;
+        uz[i] = z[i] / mag;
+        uy[i] = 0.;
+    }
+}
+
+void orc_tracecyl(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+                  double *uy, double *uz, int64_t num, double rad)
+{
+    cyl_core(NULL, x, y, z, l, m, n, ux, uy, uz, num, rad, 0.);
+}
+
+void orc_tracecylopd(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                     double *ux, double *uy, double *uz, int64_t num, double rad, double nr)
+{
+    cyl_core(opd, x, y, z, l, m, n, ux, uy, uz, num, rad, nr);
+}
+
+/* surfacesf.f95:251-296 (Newton, tol 1.e-10 fp32 literal, no iteration cap in the reference) */
+void orc_cylconic(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                  double *ux, double *uy, double *uz, int64_t num, double rad, double k)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double delt = 100., Fx = 0., Fy = 0., Fp;
+        int it = 0;
+        while (fabs(delt) > TOL_1EM10 && it < ORC_NEWTON_CAP) {
+            double q = 1 - (1 + k) * (rad * rad) * (x[i] * x[i]);
+            double low = 1 + sqrt(q);
+            double high = rad * (x[i] * x[i]);
+            double dL = -((1 + k) * (rad * rad) * x[i]) / sqrt(q);
+            double dH = 2 * rad * x[i];
+            double F = y[i] - high / low;
+            Fx = (high * dL - low * dH) / (low * low);
+            Fy = 1.;
+            Fp = Fx * l[i] + Fy * m[i];
+            delt = -F / Fp;
+            x[i] = x[i] + l[i] * delt;
+            y[i] = y[i] + m[i] * delt;
+            z[i] = z[i] + n[i] * delt;
+            it++;
+        }
+        Fp = sqrt(Fx * Fx + Fy * Fy);
+        ux[i] = Fx / Fp;
+        uy[i] = Fy / Fp;
+        uz[i] = 0.;
+    }
+}
+
+/* surfacesf.f95:423-439 / 443-459 */
+void orc_paraxial(const double *x, const double *y, double *l, double *m, int64_t num, double F, int yonly)
+{
+    for (int64_t i = 0; i < num; i++) {
+        if (!yonly) l[i] = l[i] - x[i] / F;
+        m[i] = m[i] - y[i] / F;
+    }
+}
+
+/* transformationsf.f95:32-55 */
+static void rotateaxis(double *x, double *y, double *z, double theta, double *ux, double *uy, double *uz)
+{
+    double mag = sqrt(*ux * *ux + *uy * *uy + *uz * *uz);
+    *ux = *ux / mag;
+    *uy = *uy / mag;
+    *uz = *uz / mag;
+    double c = cos(theta), s = sin(theta);
+    double o1 = (c + *ux * *ux * (1 - c)) * *x + (*ux * *uy * (1 - c) - *uz * s) * *y + (*ux * *uz * (1 - c) + *uy * s) * *z;
+    double o2 = (*uy * *ux * (1 - c) + *uz * s) * *x + (c + *uy * *uy * (1 - c)) * *y + (*uy * *uz * (1 - c) - *ux * s) * *z;
+    double o3 = (*uz * *ux * (1 - c) - *uy * s) * *x + (*uz * *uy * (1 - c) + *ux * s) * *y + (c + *uz * *uz * (1 - c)) * *z;
+    *x = o1;
+    *y = o2;
+    *z = o3;
+}
+
+/* transformationsf.f95:82-130 */
+void orc_refract(double *l, double *m, double *n, double *ux, double *uy, double *uz, int64_t num,
+                 double n1, double n2)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double dot = l[i] * ux[i] + m[i] * uy[i] + n[i] * uz[i];
+        if (dot < 0) {
+            ux[i] = -ux[i];
+            uy[i] = -uy[i];
+            uz[i] = -uz[i];
+            dot = -dot;
+        }
+        if (dot == 1) continue;
+        double t1 = acos(dot);
+        double t2 = asin((n1 / n2) * sin(t1));
+        double cx = uy[i] * n[i] - m[i] * uz[i];
+        double cy = l[i] * uz[i] - ux[i] * n[i];
+        double cz = ux[i] * m[i] - l[i] * uy[i];
+        double dt = t2 - t1;
+        rotateaxis(&l[i], &m[i], &n[i], dt, &cx, &cy, &cz);
+        double alpha = sqrt(l[i] * l[i] + m[i] * m[i] + n[i] * n[i]);
+        l[i] = l[i] / alpha;
+        m[i] = m[i] / alpha;
+        n[i] = n[i] / alpha;
+    }
+}

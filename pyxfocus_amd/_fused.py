@@ -30,14 +30,21 @@ _tls = threading.local()
 
 OPCODES = {"pxf_flat": 1, "pxf_flatopd": 2, "pxf_conic": 3, "pxf_conicopd": 4, "pxf_wolterprimary": 5,
            "pxf_wolterprimaryopd": 6, "pxf_woltersecondary": 7, "pxf_transform": 8, "pxf_itransform": 9,
-           "pxf_reflect": 10, "pxf_radgrat": 11, "pxf_radgratw": 12}
+           "pxf_reflect": 10, "pxf_radgrat": 11, "pxf_radgratw": 12, "pxf_spocone": 13, "pxf_tracesphere": 14,
+           "pxf_tracesphereopd": 15, "pxf_tracecyl": 16, "pxf_tracecylopd": 17, "pxf_cylconic": 18,
+           "pxf_paraxial": 19, "pxf_paraxialy": 20, "pxf_grat": 21, "pxf_refract": 22}
 # bundle slots (opd=0, x=1 ... uz=9) of the columns each entry point takes, in call order
 SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5, 6, 7, 8, 9, 0),
          "pxf_conic": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_conicopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9),
          "pxf_wolterprimary": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_wolterprimaryopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9),
          "pxf_woltersecondary": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_transform": (1, 2, 3, 4, 5, 6, 7, 8, 9),
          "pxf_itransform": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_reflect": (4, 5, 6, 7, 8, 9),
-         "pxf_radgrat": (1, 2, 4, 5, 6), "pxf_radgratw": (1, 2, 4, 5, 6, -1)}
+         "pxf_radgrat": (1, 2, 4, 5, 6), "pxf_radgratw": (1, 2, 4, 5, 6, -1),
+         "pxf_spocone": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_tracesphere": (1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_tracesphereopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_tracecyl": (1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_tracecylopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_cylconic": (1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_paraxial": (1, 2, 4, 5), "pxf_paraxialy": (2, 5), "pxf_grat": (4, 5, 6, -1),
+         "pxf_refract": (4, 5, 6, 7, 8, 9)}
 MAX_OPS = 32
 
 
@@ -82,7 +89,7 @@ class _Recorder:
         op.code = OPCODES[name]
         op.mask = mask.data_ptr() if mask is not None else None
         op.aux = aux.data_ptr() if aux is not None else None
-        for i, v in enumerate(tail):
+        for i, v in enumerate(t for t in tail if t is not None):
             op.a[i] = float(v)
         self.ops.append(op)
         self.keep.extend(t for t in (mask, aux) if t is not None)

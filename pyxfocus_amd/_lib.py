@@ -30,6 +30,16 @@ _SIGS = {
     "pxf_flatopd": [_P] * 10 + [_i64, _d, _P, _P],
     "pxf_conic": [_P] * 9 + [_i64, _d, _d, _P, _P],
     "pxf_conicopd": [_P] * 10 + [_i64, _d, _d, _d, _P, _P],
+    "pxf_tracesphere": [_P] * 9 + [_i64, _d, _P, _P],
+    "pxf_tracesphereopd": [_P] * 10 + [_i64, _d, _d, _P, _P],
+    "pxf_tracecyl": [_P] * 9 + [_i64, _d, _P, _P],
+    "pxf_tracecylopd": [_P] * 10 + [_i64, _d, _d, _P, _P],
+    "pxf_cylconic": [_P] * 9 + [_i64, _d, _d, _P, _P],
+    "pxf_paraxial": [_P] * 4 + [_i64, _d, _P, _P],
+    "pxf_paraxialy": [_P] * 2 + [_i64, _d, _P, _P],
+    "pxf_spocone": [_P] * 9 + [_i64, _d, _d, _P, _P],
+    "pxf_grat": [_P] * 3 + [_i64, _d, _d, _P, _P, _P],
+    "pxf_refract": [_P] * 6 + [_i64, _d, _d, _P, _P],
     "pxf_wolter_params": [_d, _d, _d, _DP, _DP, _DP],
     "pxf_wolterprimary": [_P] * 9 + [_i64, _d, _d, _d, _P, _P],
     "pxf_wolterprimaryopd": [_P] * 10 + [_i64, _d, _d, _d, _d, _P, _P],

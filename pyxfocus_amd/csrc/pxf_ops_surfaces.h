@@ -218,6 +218,202 @@ struct WolterSecondaryOp {
 };
 
 
+// ---- SPO cone : woltsurf.f95:591-638 --------------------------------------------------------
+// Closed-form quadratic; a missed ray (det < 0) gets zeroed direction cosines, position and
+// normal untouched.  R xyz lmn  W xyz u / lmn   = 96 B/ray
+struct SpoConeOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = POS | DIR;
+    static constexpr unsigned WR = POS | DIR | NRM;
+    double R0, sl, ctg, stg;  // sl = tan(tg), cos(tg), sin(tg): host libm
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double *c = r[k].c;
+            const double x = c[X], y = c[Y], z = c[Z], l = c[L], m = c[M], n = c[N];
+            const double sl2 = sl * sl;
+            const double A = n * n * sl2 - m * m - l * l;
+            const double Bq = 2 * n * sl * R0 + 2 * z * sl2 * n - 2 * x * l - 2 * y * m;
+            const double C = R0 * R0 + 2 * sl * R0 * z + z * z * sl2 - x * x - y * y;
+            const double det = Bq * Bq - 4 * A * C;
+            if (det >= 0) {
+                const double sq = sqrt(det);
+                double t1 = (-Bq + sq) / (2 * A);
+                const double t2 = (-Bq - sq) / (2 * A);
+                if (fabs(t2) < fabs(t1)) t1 = t2;
+                const double xn = x + t1 * l, yn = y + t1 * m;
+                c[X] = xn;
+                c[Y] = yn;
+                c[Z] = z + t1 * n;
+                const double rr = sqrt(xn * xn + yn * yn);
+                c[UX] = -xn / rr * ctg;
+                c[UY] = -yn / rr * ctg;
+                c[UZ] = stg;
+                wm[k] = POS | NRM;
+            } else {
+                c[L] = 0.;
+                c[M] = 0.;
+                c[N] = 0.;
+                wm[k] = DIR;
+            }
+        }
+    }
+};
+
+// ---- sphere / cylinder about the origin : surfacesf.f95:57-148 / 153-246 ------------------------
+// A miss zeroes position AND direction; the normal is then 0/0 = NaN, as in the reference.
+// R xyz lmn (+opd)  W xyz lmn u (+opd)  = 120 B/ray (+16)
+template <bool WOPD, bool CYL>
+struct SphereCylOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
+    static constexpr unsigned WR = POS | DIR | NRM | (WOPD ? B(OPD) : 0u);
+    double rad, nr;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double *c = r[k].c;
+            double x = c[X], y = c[Y], z = c[Z];
+            const double l = c[L], m = c[M], n = c[N];
+            bool hit;
+            double d1 = 0.;
+            if (!CYL) {
+                const double dotol = l * x + m * y + n * z;
+                const double mago = x * x + y * y + z * z;
+                const double det = dotol * dotol - mago + rad * rad;
+                hit = !(det < 0);
+                if (hit) {
+                    const double sq = sqrt(det);
+                    d1 = -dotol + sq;
+                    const double d2 = -dotol - sq;
+                    if (fabs(d2) < fabs(d1)) d1 = d2;
+                }
+            } else {
+                const double a = l * l + n * n;
+                const double b = 2 * (x * l + z * n);
+                const double cc = x * x + z * z - rad * rad;
+                const double det = b * b - 4 * a * cc;
+                hit = !(det < 0);
+                if (hit) {
+                    const double sq = sqrt(det);
+                    d1 = (-b + sq) / 2 / a;
+                    const double d2 = (-b - sq) / 2 / a;
+                    if (fabs(d2) < fabs(d1)) d1 = d2;
+                }
+            }
+            if (hit) {
+                if (!CYL) {
+                    x = x + d1 * l;
+                    y = y + d1 * m;
+                    z = z + d1 * n;
+                } else {
+                    x = x + l * d1;
+                    y = y + m * d1;
+                    z = z + n * d1;
+                }
+                if (WOPD) c[OPD] = c[OPD] + d1 * nr;
+            } else {
+                x = y = z = 0.;
+                c[L] = c[M] = c[N] = 0.;
+            }
+            c[X] = x;
+            c[Y] = y;
+            c[Z] = z;
+            if (!CYL) {
+                const double mago = sqrt(x * x + y * y + z * z);
+                c[UX] = x / mago;
+                c[UY] = y / mago;
+                c[UZ] = z / mago;
+            } else {
+                const double mag = sqrt(x * x + z * z);
+                c[UX] = x / mag;
+                c[UZ] = z / mag;
+                c[UY] = 0.;
+            }
+            wm[k] = hit ? (POS | NRM | (WOPD ? B(OPD) : 0u)) : (POS | DIR | NRM);
+        }
+    }
+};
+
+// ---- cylindrical conic : surfacesf.f95:251-296 (Newton, tol 1.e-10, stale-gradient normal) -----
+struct CylConicOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = POS | DIR;
+    static constexpr unsigned WR = POS | NRM;
+    double rad, k1r2;  // k1r2 = (1+k)*rad**2
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+        bool act[V];
+        double Fx[V], Fy[V];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            act[k] = sel[k];
+            any |= act[k];
+            Fx[k] = Fy[k] = 0.;
+        }
+        for (int it = 0; any && it < kNewtonCap; it++) {
+            any = false;
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                if (act[k]) {
+                    double *c = r[k].c;
+                    const double x = c[X];
+                    const double q = 1 - k1r2 * (x * x);
+                    const double sq = sqrt(q);
+                    const double low = 1 + sq;
+                    const double high = rad * (x * x);
+                    const double dL = -(k1r2 * x) / sq;
+                    const double dH = 2 * rad * x;
+                    const double F = c[Y] - high / low;
+                    Fx[k] = (high * dL - low * dH) / (low * low);
+                    Fy[k] = 1.;
+                    const double Fp = Fx[k] * c[L] + Fy[k] * c[M];
+                    const double delt = -F / Fp;
+                    c[X] = x + c[L] * delt;
+                    c[Y] = c[Y] + c[M] * delt;
+                    c[Z] = c[Z] + c[N] * delt;
+                    act[k] = fabs(delt) > PXF_TOL_1EM10;
+                    any |= act[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const double Fp = sqrt(Fx[k] * Fx[k] + Fy[k] * Fy[k]);
+            r[k].c[UX] = Fx[k] / Fp;
+            r[k].c[UY] = Fy[k] / Fp;
+            r[k].c[UZ] = 0.;
+            wm[k] = WR;
+        }
+    }
+};
+
+// ---- ideal paraxial lens : surfacesf.f95:423-439 / 443-459 --------------------------------------
+template <bool YONLY>
+struct ParaxialOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = (YONLY ? 0u : (B(X) | B(L))) | B(Y) | B(M);
+    static constexpr unsigned WR = (YONLY ? 0u : B(L)) | B(M);
+    double F;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double *c = r[k].c;
+            if (!YONLY) c[L] = c[L] - c[X] / F;
+            c[M] = c[M] - c[Y] / F;
+            wm[k] = WR;
+        }
+    }
+};
+
 // host: Van Speybroeck constants -> the Ops' precomputed scalars (woltsurf.f95:18-23,31,137-140)
 template <bool WOPD>
 inline WolterPrimaryOp<WOPD> make_wolter_primary(double r0, double z0, double psi, double nr)

@@ -152,6 +152,82 @@ struct RadgratOp {
     }
 };
 
+// grat : transformationsf.f95:277-305 (linear grating, grooves along y).  The Fortran takes
+// per-ray `order` and `wave` arrays; only their product enters (l - order*wave/d), so the entry
+// takes either a scalar product or a per-ray product column (AUX).  Evanescent -> zeroed cosines.
+// R l m n (+ow)  W l m n  = 48 B/ray (56)
+template <bool OWCOL>
+struct GratOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = DIR | (OWCOL ? B(AUX) : 0u);
+    static constexpr unsigned WR = DIR;
+    double d, ow;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double *c = r[k].c;
+            const double sn = c[N] / fabs(c[N]);
+            const double prod = OWCOL ? c[AUX] : ow;
+            const double l = c[L] - prod / d, m = c[M];
+            double n = sn * sqrt(1 - l * l - m * m);
+            const bool evan = (l * l + m * m) > 1;
+            c[L] = evan ? 0. : l;
+            c[M] = evan ? 0. : m;
+            c[N] = evan ? 0. : n;
+            wm[k] = WR;
+        }
+    }
+};
+
+// refract : transformationsf.f95:82-130 (+ rotateaxis :32-55).  Snell rotation of the direction
+// about (u x d); the normal is flipped to the far side first.  acos/asin/sin/cos come from ocml,
+// so parity is to ~1e-15, not bitwise.  Total internal reflection -> NaN, as in the reference.
+// R lmn u  W lmn u = 96 B/ray
+struct RefractOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = DIR | NRM;
+    static constexpr unsigned WR = DIR | NRM;
+    double n1, n2;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double *c = r[k].c;
+            double dot = c[L] * c[UX] + c[M] * c[UY] + c[N] * c[UZ];
+            if (dot < 0) {
+                c[UX] = -c[UX];
+                c[UY] = -c[UY];
+                c[UZ] = -c[UZ];
+                dot = -dot;
+            }
+            wm[k] = WR;
+            if (dot == 1) continue;
+            const double t1 = acos(dot);
+            const double t2 = asin((n1 / n2) * sin(t1));
+            double ax = c[UY] * c[N] - c[M] * c[UZ];
+            double ay = c[L] * c[UZ] - c[UX] * c[N];
+            double az = c[UX] * c[M] - c[L] * c[UY];
+            const double dt = t2 - t1;
+            const double mag = sqrt(ax * ax + ay * ay + az * az);
+            ax = ax / mag;
+            ay = ay / mag;
+            az = az / mag;
+            const double cs = cos(dt), sn = sin(dt);
+            const double x = c[L], y = c[M], z = c[N];
+            const double o1 = (cs + ax * ax * (1 - cs)) * x + (ax * ay * (1 - cs) - az * sn) * y + (ax * az * (1 - cs) + ay * sn) * z;
+            const double o2 = (ay * ax * (1 - cs) + az * sn) * x + (cs + ay * ay * (1 - cs)) * y + (ay * az * (1 - cs) - ax * sn) * z;
+            const double o3 = (az * ax * (1 - cs) - ay * sn) * x + (az * ay * (1 - cs) + ax * sn) * y + (cs + az * az * (1 - cs)) * z;
+            const double alpha = sqrt(o1 * o1 + o2 * o2 + o3 * o3);
+            c[L] = o1 / alpha;
+            c[M] = o2 / alpha;
+            c[N] = o3 / alpha;
+        }
+    }
+};
+
 // pointTo : transformations.py:91-100.   R x y z  W l m n
 struct PointToOp {
     PXF_OP_DEFAULTS

@@ -100,6 +100,26 @@ __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, 
                     run_op(RadgratOp<true>{o.p[0], o.p[1], 0., o.p[3], o.p[4]}, r, sel);
                     break;
                 }
+                case PXF_OP_SPOCONE: run_op(SpoConeOp{o.p[0], o.p[1], o.p[2], o.p[3]}, r, sel); break;
+                case PXF_OP_SPHERE: run_op(SphereCylOp<false, false>{o.p[0], 0.}, r, sel); break;
+                case PXF_OP_SPHEREOPD: run_op(SphereCylOp<true, false>{o.p[0], o.p[1]}, r, sel); break;
+                case PXF_OP_CYL: run_op(SphereCylOp<false, true>{o.p[0], 0.}, r, sel); break;
+                case PXF_OP_CYLOPD: run_op(SphereCylOp<true, true>{o.p[0], o.p[1]}, r, sel); break;
+                case PXF_OP_CYLCONIC: run_op(CylConicOp{o.p[0], o.p[1]}, r, sel); break;
+                case PXF_OP_PARAXIAL: run_op(ParaxialOp<false>{o.p[0]}, r, sel); break;
+                case PXF_OP_PARAXIALY: run_op(ParaxialOp<true>{o.p[0]}, r, sel); break;
+                case PXF_OP_GRAT:
+                    if (o.aux) {
+                        double t[V];
+                        load_col<V, NT>(o.aux, vv, t);
+#pragma unroll
+                        for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
+                        run_op(GratOp<true>{o.p[0], 0.}, r, sel);
+                    } else {
+                        run_op(GratOp<false>{o.p[0], o.p[1]}, r, sel);
+                    }
+                    break;
+                case PXF_OP_REFRACT: run_op(RefractOp{o.p[0], o.p[1]}, r, sel); break;
                 default: break;
             }
             if (masked) {  // unselected rays keep every register
@@ -215,6 +235,47 @@ static int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dro
                 o.p[1] = u.a[1];  // order
                 radgrat_consts(o.p[3], o.p[4]);
                 add(B(X) | B(Y) | DIR, DIR, 0, 0);
+                break;
+            case PXF_OP_SPOCONE:
+                o.p[0] = u.a[0];
+                o.p[1] = tan(u.a[1]);
+                o.p[2] = cos(u.a[1]);
+                o.p[3] = sin(u.a[1]);
+                add(POS | DIR, 0, POS | DIR | NRM, 0);  // miss: lmn zeroed, xyz/u kept
+                break;
+            case PXF_OP_SPHERE:
+            case PXF_OP_CYL:
+                o.p[0] = u.a[0];
+                add(POS | DIR, POS | NRM, DIR, 0);  // miss zeroes lmn too
+                break;
+            case PXF_OP_SPHEREOPD:
+            case PXF_OP_CYLOPD:
+                o.p[0] = u.a[0];
+                o.p[1] = u.a[1];
+                add(POS | DIR | B(OPD), POS | NRM, DIR | B(OPD), 0);
+                break;
+            case PXF_OP_CYLCONIC:
+                o.p[0] = u.a[0];
+                o.p[1] = (1 + u.a[1]) * (u.a[0] * u.a[0]);
+                add(POS | DIR, POS | NRM, 0, 0);
+                break;
+            case PXF_OP_PARAXIAL:
+                o.p[0] = u.a[0];
+                add(B(X) | B(Y) | B(L) | B(M), B(L) | B(M), 0, 0);
+                break;
+            case PXF_OP_PARAXIALY:
+                o.p[0] = u.a[0];
+                add(B(Y) | B(M), B(M), 0, 0);
+                break;
+            case PXF_OP_GRAT:
+                o.p[0] = u.a[0];
+                o.p[1] = u.a[1];
+                add(DIR, DIR, 0, 0);
+                break;
+            case PXF_OP_REFRACT:
+                o.p[0] = u.a[0];
+                o.p[1] = u.a[1];
+                add(DIR | NRM, DIR | NRM, 0, 0);
                 break;
             default: return PXF_EINVAL;
         }

@@ -95,4 +95,68 @@ int pxf_woltersecondary(double *x, double *y, double *z, const double *l, const 
     return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
 }
 
+int pxf_spocone(double *x, double *y, double *z, double *l, double *m, double *n, double *ux, double *uy,
+                double *uz, int64_t num, double R0, double tg, const uint8_t *mask, pxf_stream_t stream)
+{
+    return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream,
+                       SpoConeOp{R0, tan(tg), cos(tg), sin(tg)});
+}
+
+int pxf_tracesphere(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
+                    double *uy, double *uz, int64_t num, double rad, const uint8_t *mask, pxf_stream_t stream)
+{
+    return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream,
+                       SphereCylOp<false, false>{rad, 0.});
+}
+
+int pxf_tracesphereopd(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                       double *ux, double *uy, double *uz, int64_t num, double rad, double nr,
+                       const uint8_t *mask, pxf_stream_t stream)
+{
+    return launch_rays(cols9(opd, x, y, z, l, m, n, ux, uy, uz), num, mask, stream,
+                       SphereCylOp<true, false>{rad, nr});
+}
+
+int pxf_tracecyl(double *x, double *y, double *z, double *l, double *m, double *n, double *ux, double *uy,
+                 double *uz, int64_t num, double rad, const uint8_t *mask, pxf_stream_t stream)
+{
+    return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream,
+                       SphereCylOp<false, true>{rad, 0.});
+}
+
+int pxf_tracecylopd(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                    double *ux, double *uy, double *uz, int64_t num, double rad, double nr,
+                    const uint8_t *mask, pxf_stream_t stream)
+{
+    return launch_rays(cols9(opd, x, y, z, l, m, n, ux, uy, uz), num, mask, stream,
+                       SphereCylOp<true, true>{rad, nr});
+}
+
+int pxf_cylconic(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                 double *ux, double *uy, double *uz, int64_t num, double rad, double k,
+                 const uint8_t *mask, pxf_stream_t stream)
+{
+    return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream,
+                       CylConicOp{rad, (1 + k) * (rad * rad)});
+}
+
+int pxf_paraxial(const double *x, const double *y, double *l, double *m, int64_t num, double F,
+                 const uint8_t *mask, pxf_stream_t stream)
+{
+    Cols c{};
+    c.p[X] = const_cast<double *>(x);
+    c.p[Y] = const_cast<double *>(y);
+    c.p[L] = l;
+    c.p[M] = m;
+    return launch_rays(c, num, mask, stream, ParaxialOp<false>{F});
+}
+
+int pxf_paraxialy(const double *y, double *m, int64_t num, double F, const uint8_t *mask, pxf_stream_t stream)
+{
+    Cols c{};
+    c.p[Y] = const_cast<double *>(y);
+    c.p[M] = m;
+    return launch_rays(c, num, mask, stream, ParaxialOp<true>{F});
+}
+
 }  // extern "C"

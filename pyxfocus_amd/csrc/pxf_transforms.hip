@@ -194,4 +194,31 @@ int pxf_pointto(const double *x, const double *y, const double *z, double *l, do
     return launch_rays(c, num, nullptr, stream, PointToOp{x0, y0, z0, reverse});
 }
 
+int pxf_grat(double *l, double *m, double *n, int64_t num, double d, double order_times_wave,
+             const double *order_times_wave_col, const uint8_t *mask, pxf_stream_t stream)
+{
+    Cols c{};
+    c.p[L] = l;
+    c.p[M] = m;
+    c.p[N] = n;
+    if (order_times_wave_col) {
+        c.p[AUX] = const_cast<double *>(order_times_wave_col);
+        return launch_rays(c, num, mask, stream, GratOp<true>{d, 0.});
+    }
+    return launch_rays(c, num, mask, stream, GratOp<false>{d, order_times_wave});
+}
+
+int pxf_refract(double *l, double *m, double *n, double *ux, double *uy, double *uz, int64_t num, double n1,
+                double n2, const uint8_t *mask, pxf_stream_t stream)
+{
+    Cols c{};
+    c.p[L] = l;
+    c.p[M] = m;
+    c.p[N] = n;
+    c.p[UX] = ux;
+    c.p[UY] = uy;
+    c.p[UZ] = uz;
+    return launch_rays(c, num, mask, stream, RefractOp{n1, n2});
+}
+
 }  // extern "C"

@@ -49,9 +49,11 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def _call(name, cols, tail, mask=None):
+def _call(name, cols, tail, mask=None, aux_last=False):
     """cols -> device pointers, then num, then `tail` scalars, then mask, stream.
-    Inside a `pyxfocus_amd.fused()` block the call is recorded instead (see _fused.py)."""
+    Inside a `pyxfocus_amd.fused()` block the call is recorded instead (see _fused.py).
+    aux_last: the last entry of `cols` is an extra per-ray column that the C entry takes AFTER the
+    scalars (pxf_grat's order*wave column)."""
     num, dev = _check_cols(cols, name)
     mp = _mask_ptr(mask, num, dev, name)
     rec = fused.active()
@@ -64,8 +66,10 @@ def _call(name, cols, tail, mask=None):
         if rec.try_add(name, cols, tail, mask):
             return
     h = _lib.lib()
+    ptrs = [t.data_ptr() for t in cols]
+    extra = [ptrs.pop()] if aux_last else []
     with torch.cuda.device(dev):
-        rc = getattr(h, name)(*[t.data_ptr() for t in cols], num, *tail, mp, _stream(dev))
+        rc = getattr(h, name)(*ptrs, num, *tail, *extra, mp, _stream(dev))
     _lib.check(rc, name)
 
 
@@ -86,7 +90,43 @@ def conicopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, nr, mask=None):
     _call("pxf_conicopd", (opd, x, y, z, l, m, n, ux, uy, uz), (float(R), float(K), float(nr)), mask)
 
 
+def tracesphere(x, y, z, l, m, n, ux, uy, uz, rad, mask=None):
+    _call("pxf_tracesphere", (x, y, z, l, m, n, ux, uy, uz), (float(rad),), mask)
+
+
+def tracesphereopd(opd, x, y, z, l, m, n, ux, uy, uz, rad, nr, mask=None):
+    _call("pxf_tracesphereopd", (opd, x, y, z, l, m, n, ux, uy, uz), (float(rad), float(nr)), mask)
+
+
+def tracecyl(x, y, z, l, m, n, ux, uy, uz, rad, mask=None):
+    _call("pxf_tracecyl", (x, y, z, l, m, n, ux, uy, uz), (float(rad),), mask)
+
+
+def tracecylopd(opd, x, y, z, l, m, n, ux, uy, uz, rad, nr, mask=None):
+    _call("pxf_tracecylopd", (opd, x, y, z, l, m, n, ux, uy, uz), (float(rad), float(nr)), mask)
+
+
+def cylconic(x, y, z, l, m, n, ux, uy, uz, rad, k, mask=None):
+    _call("pxf_cylconic", (x, y, z, l, m, n, ux, uy, uz), (float(rad), float(k)), mask)
+
+
+def paraxial(x, y, z, l, m, n, ux, uy, uz, F, mask=None):
+    # f2py signature takes all nine columns; the loop touches x, y, l, m only (surfacesf.f95:431-436)
+    _check_cols((x, y, z, l, m, n, ux, uy, uz), "pxf_paraxial")
+    _call("pxf_paraxial", (x, y, l, m), (float(F),), mask)
+
+
+def paraxialy(x, y, z, l, m, n, ux, uy, uz, F, mask=None):
+    _check_cols((x, y, z, l, m, n, ux, uy, uz), "pxf_paraxialy")
+    _call("pxf_paraxialy", (y, m), (float(F),), mask)
+
+
 # ---- woltsurf -------------------------------------------------------------------------------
+def spocone(x, y, z, l, m, n, ux, uy, uz, R0, tg, mask=None):
+    _call("pxf_spocone", (x, y, z, l, m, n, ux, uy, uz), (float(R0), float(tg)), mask)
+
+
+
 def wolterprimary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, mask=None):
     _call("pxf_wolterprimary", (x, y, z, l, m, n, ux, uy, uz), (float(r0), float(z0), float(psi)), mask)
 
@@ -163,13 +203,31 @@ def radgrat(x, y, l, m, n, wave, dpermm, order, mask=None):
     _lib.check(rc, "pxf_radgrat")
 
 
+def grat(x, y, l, m, n, d, order, wave, mask=None):
+    """f2py signature grat(x,y,l,m,n,d,order,wave) (transformationsf.f95:277).  `order` and `wave`
+    may each be a scalar or a per-ray column; only their product enters the loop."""
+    num, dev = _check_cols((x, y, l, m, n), "pxf_grat")
+    if isinstance(order, torch.Tensor) or isinstance(wave, torch.Tensor):
+        ow = (torch.as_tensor(order, dtype=torch.float64, device=dev) *
+              torch.as_tensor(wave, dtype=torch.float64, device=dev)).expand(num).contiguous()
+        _call("pxf_grat", (l, m, n, ow), (float(d), 0.), mask, aux_last=True)
+    else:
+        _call("pxf_grat", (l, m, n), (float(d), float(order) * float(wave), None), mask)
+
+
+def refract(l, m, n, ux, uy, uz, n1, n2, mask=None):
+    _call("pxf_refract", (l, m, n, ux, uy, uz), (float(n1), float(n2)), mask)
+
+
 def radgratw(x, y, l, m, n, wave, dpermm, order, mask=None):
     _call("pxf_radgratw", (x, y, l, m, n, wave), (float(dpermm), float(order)), mask)
 
 
-surfacesf = SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd)
+surfacesf = SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd,
+                            tracesphere=tracesphere, tracesphereopd=tracesphereopd, tracecyl=tracecyl,
+                            tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial, paraxialy=paraxialy)
 woltsurf = SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
-                           woltersecondary=woltersecondary)
+                           woltersecondary=woltersecondary, spocone=spocone)
 zernsurf = SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd)
 transformationsf = SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
-                                   radgrat=radgrat, radgratw=radgratw)
+                                   radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract)

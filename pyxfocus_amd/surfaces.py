@@ -14,7 +14,8 @@ from .native import zernsurf as zern
 from .transformations import ind_to_mask
 
 __all__ = ["flat", "zernsurf", "conic", "wolterprimary", "wolterprimarynode", "woltersecondary", "focus",
-           "focusX", "focusY", "focusI", "zmodes"]
+           "focusX", "focusY", "focusI", "zmodes", "sphere", "tanSphere", "cyl", "cylconic", "paraxial",
+           "paraxialY", "spoCone", "spoPrimary", "spoSecondary"]
 
 
 def flat(rays, ind=None, nr=None):
@@ -70,6 +71,76 @@ def conic(rays, R, K, nr=None):
         surf.conicopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, nr)
     else:
         surf.conic(x, y, z, l, m, n, ux, uy, uz, R, K)
+    return
+
+
+def sphere(rays, rad, nr=None):
+    """Spherical surface centred on the origin (surfaces.py:81-89)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if nr is not None:
+        surf.tracesphereopd(opd, x, y, z, l, m, n, ux, uy, uz, rad, nr)
+    else:
+        surf.tracesphere(x, y, z, l, m, n, ux, uy, uz, rad)
+    return
+
+
+def tanSphere(rays, rad, nr=None):
+    """Spherical surface tangent to the XY plane; positive radius curves toward +Z (surfaces.py:91-102)."""
+    tran.transform(rays, 0, 0, rad, 0, 0, 0)
+    sphere(rays, rad, nr=nr)
+    tran.transform(rays, 0, 0, -rad, 0, 0, 0)
+    return
+
+
+def cyl(rays, rad, nr=None):
+    """Cylinder about the y axis through the origin (surfaces.py:166-178)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if nr is not None:
+        surf.tracecylopd(opd, x, y, z, l, m, n, ux, uy, uz, rad, nr)
+    else:
+        surf.tracecyl(x, y, z, l, m, n, ux, uy, uz, rad)
+    return
+
+
+def cylconic(rays, rad, k):
+    """Cylindrical conic (surfaces.py:180-184)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    surf.cylconic(x, y, z, l, m, n, ux, uy, uz, rad, k)
+
+
+def paraxial(rays, F):
+    """Ideal paraxial lens in the xy plane, axis along z (surfaces.py:186-194)."""
+    x, y, z, l, m, n, ux, uy, uz = rays[1:]
+    surf.paraxial(x, y, z, l, m, n, ux, uy, uz, F)
+    return
+
+
+def paraxialY(rays, F):
+    """Ideal paraxial cylindrical lens acting on y only (surfaces.py:196-204)."""
+    x, y, z, l, m, n, ux, uy, uz = rays[1:]
+    surf.paraxialy(x, y, z, l, m, n, ux, uy, uz, F)
+    return
+
+
+def spoCone(rays, R0, tg, ind=None):
+    """SPO cone with intersection radius R0 and slope angle tg; the XY plane is the SPO
+    intersection plane (surfaces.py:403-419)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    wolt.spocone(x, y, z, l, m, n, ux, uy, uz, R0, tg, mask=ind_to_mask(ind, x.shape[0], x.device))
+    return
+
+
+def spoPrimary(rays, R0, F, d=.605, ind=None):
+    """SPO primary with intersection radius R0 and focal length F (surfaces.py:421-430)."""
+    tg = .25 * np.arctan((R0 + d / 2) / F)
+    spoCone(rays, R0, tg, ind=ind)
+    return
+
+
+def spoSecondary(rays, R0, F, d=.605, ind=None):
+    """SPO secondary with intersection radius R0 and focal length F (surfaces.py:432-441)."""
+    tg = .75 * np.arctan((R0 + d / 2) / F)
+    spoCone(rays, R0, tg, ind=ind)
     return
 
 

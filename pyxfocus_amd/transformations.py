@@ -25,7 +25,8 @@ from . import _fused as fused
 from . import _lib, native
 from .native import transformationsf as tran
 
-__all__ = ["copy_rays", "transform", "itransform", "steerX", "steerY", "pointTo", "reflect", "radgrat",
+__all__ = ["copy_rays", "transform", "itransform", "steerX", "steerY", "pointTo", "reflect", "refract", "grat",
+           "radgrat",
            "vignette", "newCoords", "rotationM", "translationM", "applyT", "applyTPos"]
 
 
@@ -151,6 +152,29 @@ def reflect(rays, ind=None):
     """Reflect rays based on surface normal (transformations.py:102-112)"""
     l, m, n, ux, uy, uz = rays[4:]
     tran.reflect(l, m, n, ux, uy, uz, mask=ind_to_mask(ind, l.shape[0], _dev(rays)))
+    return
+
+
+def refract(rays, n1, n2):
+    """Refract rays at the current surface normal from index n1 into index n2
+    (transformations.py:114-121)."""
+    l, m, n, ux, uy, uz = rays[4:]
+    tran.refract(l, m, n, ux, uy, uz, n1, n2)
+    return
+
+
+def grat(rays, d, order, wave, ind=None):
+    """Linear grating with groove direction +y and period d; evanescence zeroes the direction
+    cosines (transformations.py:200-212).  The reference's Fortran declares `order` and `wave`
+    as per-ray arrays while its wrapper documents scalars; here each may be a
+    scalar or an array with one entry per ray."""
+    x, y, z, l, m, n = rays[1:7]
+    dev = _dev(rays)
+    mask = ind_to_mask(ind, x.shape[0], dev)
+    arr = [isinstance(v, (np.ndarray, torch.Tensor, list, tuple)) for v in (order, wave)]
+    if any(arr):
+        order, wave = [_as_tensor(v, dev).to(torch.float64) if a else v for v, a in zip((order, wave), arr)]
+    tran.grat(x, y, l, m, n, d, order, wave, mask=mask)
     return
 
 

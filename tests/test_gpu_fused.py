@@ -151,3 +151,41 @@ def test_fused_more_ops_than_one_program_holds():
             tran.transform(b, .1, 0, 0, 0, 0, 1e-3 * i)
     assert rec.launches == 3 and rec.fused_ops == 75
     same(a, b)
+
+
+def test_fused_batch1_ops_equal_eager():
+    """SPO cones, linear grating, sphere, cylinder, paraxial lens, refraction in one program."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(23)
+    n = 150_001
+    c = cases.annulus_rays(rng, n, 599.6, 601.2, 150.)
+    c["l"] = rng.normal(0, 2e-4, n); c["m"] = rng.normal(0, 2e-4, n)
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    c["m"][:7] = 1.; c["l"][:7] = 0.; c["n"][:7] = 0.; c["x"][:7] = 5e4          # miss the cone
+    m1 = rng.random(n) < .6
+    ow = rng.uniform(-3, 3, n)
+
+    def program(r):
+        surf.spoPrimary(r, 600., 12000.)
+        tran.reflect(r)
+        tran.transform(r, 0, 0, -30., 0, 0, 0)
+        surf.spoSecondary(r, 600., 12000., ind=m1)
+        tran.reflect(r, ind=m1)
+        tran.grat(r, 160., 1., 2.4)
+        tran.grat(r, 200., ow, 1., ind=m1)
+        surf.paraxial(r, 1e4)
+        surf.paraxialY(r, -2e4)
+        tran.transform(r, 0, 0, -500., 0, 0, 0)
+        surf.sphere(r, 900., nr=1.5)
+        tran.refract(r, 1., 1.5)
+        surf.cyl(r, 2000.)
+        surf.flat(r)
+
+    a, b = dev_rays(c), dev_rays(c)
+    program(a)
+    with pxf.fused() as rec:
+        program(b)
+    assert rec.launches == 1 and rec.fused_ops == 14
+    same(a, b)

@@ -365,3 +365,55 @@ def test_graze_and_ind_angle():
     assert np.abs(anal.grazeAngle(rays, ind=ind).cpu().numpy() - (np.pi / 2 - np.arccos(dot[ind]))).max() < 1e-14
     nrm = (0., 0., 1.)
     assert np.abs(anal.indAngle(rays, normal=nrm).cpu().numpy() - np.arccos(c["n"])).max() < 1e-14
+
+
+def test_batch1_wrappers_vs_oracle(port):
+    """surfaces.spoPrimary/spoSecondary/sphere/tanSphere/cyl/cylconic/paraxial*, transformations.grat/
+    refract: wrapper-level calls against the oracle's native entry points."""
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from oracle import cases
+    rng = np.random.default_rng(31)
+    n = 20_001
+    c = cases.annulus_rays(rng, n, 599.6, 601.2, 150.)
+    c["l"] = rng.normal(0, 2e-4, n); c["m"] = rng.normal(0, 2e-4, n)
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    a = [c[k] for k in ALLCOLS[1:]]
+    T, S = port.transformationsf, port.surfacesf
+    ind = rng.random(n) < .5
+    # SPO pair; secondary only on a subset (ind)
+    surf.spoPrimary(rays, 600., 12000.)
+    port.woltsurf.spocone(*a, 600., .25 * np.arctan((600. + .605 / 2) / 12000.))
+    tran.reflect(rays); T.reflect(*a[3:])
+    sub = [np.ascontiguousarray(v[ind]) for v in a]
+    port.woltsurf.spocone(*sub, 600., .75 * np.arctan((600. + .605 / 2) / 12000.))
+    for v, s_ in zip(a, sub):
+        v[ind] = s_
+    surf.spoSecondary(rays, 600., 12000., ind=ind)
+    # linear grating: scalar and per-ray order
+    tran.grat(rays, 160., 1., 2.4)
+    T.grat(c["x"], c["y"], c["l"], c["m"], c["n"], 160., 1., 2.4)
+    orders = rng.choice([-1., 0., 1., 2.], n)
+    tran.grat(rays, 250., orders, 1.7)
+    T.grat(c["x"], c["y"], c["l"], c["m"], c["n"], 250., orders, np.full(n, 1.7))
+    surf.paraxial(rays, 5e3); S.paraxial(*a, 5e3)
+    surf.paraxialY(rays, -7e3); S.paraxialy(*a, -7e3)
+    # tanSphere = transform + sphere + transform (surfaces.py:91-102), OPD variant
+    surf.tanSphere(rays, -800., nr=1.2)
+    T.transform(*a, 0., 0., 800., 0., 0., 0.); S.tracesphereopd(c["opd"], *a, -800., 1.2); T.transform(*a, 0., 0., -800., 0., 0., 0.)
+    surf.cyl(rays, 3000.); S.tracecyl(*a, 3000.)
+    for k, r in zip(ALLCOLS, host(rays)):
+        assert bits_equal(r, c[k]).all(), k
+    tran.refract(rays, 1., 1.45); T.refract(*a[3:], 1., 1.45)
+    for k, r in zip(ALLCOLS, host(rays)):
+        f = ~np.isnan(c[k])
+        assert (np.isnan(r) == np.isnan(c[k])).all() and np.abs(r[f] - c[k][f]).max() < 1e-14, k
+    # cylconic
+    for name, fn, cols, args in cases.cases(num=3000, seed=9):
+        if name == "cylconic":
+            rays = [torch.from_numpy(cols[k].copy()).cuda() for k in ALLCOLS]
+            surf.cylconic(rays, *args)
+            cases.call(port, fn, cols, args)
+            for k, r in zip(ALLCOLS, host(rays)):
+                assert bits_equal(r, cols[k]).all(), k

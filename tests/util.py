@@ -6,13 +6,18 @@ ALLCOLS = "opd x y z l m n ux uy uz".split()
 # functions whose HIP kernels are bit-identical to the reference (add/mul/div/sqrt only, no FMA)
 BITWISE = {"surfacesf.flat", "surfacesf.flatopd", "surfacesf.conic", "surfacesf.conicopd",
            "woltsurf.wolterprimary", "woltsurf.wolterprimaryopd", "woltsurf.woltersecondary",
-           "transformationsf.transform", "transformationsf.itransform", "transformationsf.reflect"}
+           "transformationsf.transform", "transformationsf.itransform", "transformationsf.reflect",
+           "woltsurf.spocone", "transformationsf.grat", "surfacesf.tracesphere", "surfacesf.tracesphereopd",
+           "surfacesf.tracecyl", "surfacesf.tracecylopd", "surfacesf.cylconic", "surfacesf.paraxial",
+           "surfacesf.paraxialy"}
 # tolerance-parity functions: |gpu - ref| <= atol + rtol*|ref| + cond/|ref| per column.
 # radgrat: l, m agree to an ulp; n = sn*sqrt(1-l^2-m^2) is ill-conditioned at grazing incidence
 # (|n| -> 0): a 1-ulp (1.1e-16) difference in m moves n by 1.1e-16/|n|, hence the cond term on n.
 TOL = {"transformationsf.radgrat": (1e-14, 1e-13, {"n": 3e-16}),
        "transformationsf.radgratw": (1e-14, 1e-13, {"n": 3e-16}),
-       "zernsurf.tracezern": (2e-11, 1e-12, {}), "zernsurf.tracezernopd": (2e-11, 1e-12, {})}
+       "zernsurf.tracezern": (2e-11, 1e-12, {}), "zernsurf.tracezernopd": (2e-11, 1e-12, {}),
+       # refract: acos/asin/sin/cos from ocml instead of glibc
+       "transformationsf.refract": (2e-15, 1e-14, {})}
 
 
 def bits_equal(a, b):
@@ -60,8 +65,8 @@ def call_gpu(fn_path, tcols, args, mask=None):
     import torch
     a2 = []
     for a in args:
-        if fn_path == "transformationsf.radgratw" and isinstance(a, np.ndarray) and a.ndim == 1 and \
-                a.dtype == np.float64 and len(a) == len(arrs[0]):
+        if fn_path in ("transformationsf.radgratw", "transformationsf.grat") and isinstance(a, np.ndarray) \
+                and a.ndim == 1 and a.dtype == np.float64 and len(a) == len(arrs[0]):
             a = torch.from_numpy(a).to(arrs[0].device)
         a2.append(a)
     f(*arrs, *a2, mask=mask)
