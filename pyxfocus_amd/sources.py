@@ -40,16 +40,24 @@ def _pack(cols, device):
     return [torch.from_numpy(np.array(c, dtype=np.float64, order="C", copy=True)).to(dev) for c in cols]
 
 
-def _philox(kind, num, p, seed, first_index, device):
-    dev = _device(device)
-    if dev.type != "cuda":
-        raise _lib.PxfError("rng='philox' generates on the GPU; device must be a ROCm device")
+def _philox(kind, num, p, seed, first_index, device, out=None):
     num = int(num)
-    buf = torch.empty((10, num), dtype=torch.float64, device=dev)   # one allocation, ten SoA columns
-    if num % 2:   # keep every column 16-byte aligned for the 2-rays-per-lane kernels
-        rays = [torch.empty(num, dtype=torch.float64, device=dev) for _ in range(10)]
+    if out is not None:
+        # generate INTO an existing bundle (e.g. one shell's slice of a multi-shell bundle)
+        rays = list(out)
+        if len(rays) != 10 or any((not t.is_cuda) or t.dtype != torch.float64 or t.dim() != 1 or
+                                  t.shape[0] != num or not t.is_contiguous() for t in rays):
+            raise ValueError("out= must be ten contiguous float64 device columns of length num")
+        dev = rays[0].device
     else:
-        rays = [buf[i] for i in range(10)]
+        dev = _device(device)
+        if dev.type != "cuda":
+            raise _lib.PxfError("rng='philox' generates on the GPU; device must be a ROCm device")
+        if num % 2:   # keep every column 16-byte aligned for the 2-rays-per-lane kernels
+            rays = [torch.empty(num, dtype=torch.float64, device=dev) for _ in range(10)]
+        else:
+            buf = torch.empty((10, num), dtype=torch.float64, device=dev)   # one allocation, ten SoA columns
+            rays = [buf[i] for i in range(10)]
     arr = (C.c_void_p * 10)(*[r.data_ptr() for r in rays])
     p = list(p) + [0.] * (4 - len(p))
     with torch.cuda.device(dev):
@@ -60,10 +68,10 @@ def _philox(kind, num, p, seed, first_index, device):
     return rays
 
 
-def pointsource(ang, num, device=None, rng="numpy", seed=0, first_index=0):
+def pointsource(ang, num, device=None, rng="numpy", seed=0, first_index=0, out=None):
     """Point source with half-angle divergence `ang`; rays point in +z (sources.py:20-53)."""
     if rng == "philox":
-        return _philox("pointsource", num, (ang,), seed, first_index, device)
+        return _philox("pointsource", num, (ang,), seed, first_index, device, out=out)
     rho = np.sqrt(np.random.rand(num)) * np.sin(ang)
     theta = np.random.rand(num) * 2 * np.pi
     l = rho * np.cos(theta)
@@ -73,10 +81,10 @@ def pointsource(ang, num, device=None, rng="numpy", seed=0, first_index=0):
     return _pack([zero, zero, zero, zero, l, m, n, zero, zero, zero], device)
 
 
-def circularbeam(rad, num, device=None, rng="numpy", seed=0, first_index=0):
+def circularbeam(rad, num, device=None, rng="numpy", seed=0, first_index=0, out=None):
     """Uniform circular beam of radius `rad`; rays point in +z (sources.py:56-88)."""
     if rng == "philox":
-        return _philox("circularbeam", num, (rad,), seed, first_index, device)
+        return _philox("circularbeam", num, (rad,), seed, first_index, device, out=out)
     rho = np.sqrt(np.random.rand(num)) * rad
     theta = np.random.rand(num) * 2 * np.pi
     zero = np.repeat(0., num)
@@ -84,10 +92,10 @@ def circularbeam(rad, num, device=None, rng="numpy", seed=0, first_index=0):
                   zero, zero, zero], device)
 
 
-def annulus(rin, rout, num, zhat=-1., device=None, rng="numpy", seed=0, first_index=0):
+def annulus(rin, rout, num, zhat=-1., device=None, rng="numpy", seed=0, first_index=0, out=None):
     """Annulus of rays, uniform in area; default pointing -z (sources.py:91-127)."""
     if rng == "philox":
-        return _philox("annulus", num, (rin, rout, 0., zhat), seed, first_index, device)
+        return _philox("annulus", num, (rin, rout, 0., zhat), seed, first_index, device, out=out)
     rho = np.sqrt(rin ** 2 + np.random.rand(num) * (rout ** 2 - rin ** 2))
     theta = np.random.rand(num) * 2 * np.pi
     zero = np.repeat(0., num)
@@ -95,11 +103,11 @@ def annulus(rin, rout, num, zhat=-1., device=None, rng="numpy", seed=0, first_in
                   zero, zero, zero], device)
 
 
-def subannulus(rin, rout, dphi, num, zhat=1., device=None, rng="numpy", seed=0, first_index=0):
+def subannulus(rin, rout, dphi, num, zhat=1., device=None, rng="numpy", seed=0, first_index=0, out=None):
     """Sub-apertured annulus of full angular width dphi centred on +x; default pointing +z
     (sources.py:130-170)."""
     if rng == "philox":
-        return _philox("subannulus", num, (rin, rout, dphi, zhat), seed, first_index, device)
+        return _philox("subannulus", num, (rin, rout, dphi, zhat), seed, first_index, device, out=out)
     rho = np.sqrt(rin ** 2 + np.random.rand(num) * (rout ** 2 - rin ** 2))
     theta = np.random.rand(num) * dphi - dphi / 2.
     zero = np.repeat(0., num)
@@ -155,10 +163,10 @@ def convergingbeam2(zset, xmin, xmax, ymin, ymax, num, lscat, device=None):
     return _pack([zero, x, y, z, l, m, n, zero, zero, zero], device)
 
 
-def rectbeam(xhalfwidth, yhalfwidth, num, device=None, rng="numpy", seed=0, first_index=0):
+def rectbeam(xhalfwidth, yhalfwidth, num, device=None, rng="numpy", seed=0, first_index=0, out=None):
     """Uniform rectangular beam; rays point +z (sources.py:348-377)."""
     if rng == "philox":
-        return _philox("rectbeam", num, (xhalfwidth, yhalfwidth), seed, first_index, device)
+        return _philox("rectbeam", num, (xhalfwidth, yhalfwidth), seed, first_index, device, out=out)
     x = (np.random.rand(num) - .5) * 2 * xhalfwidth
     y = (np.random.rand(num) - .5) * 2 * yhalfwidth
     zero = np.repeat(0., num)

@@ -141,6 +141,98 @@ def config4(n, reps, nterms=36):
     return res
 
 
+# ---- config 5: Arcus-style multi-shell Wolter-I + grating -----------------------
+ARCUS_ANG = [[-27.653, -16.592, -5.531, 5.531, 16.592, 27.653], [-23.174, -13.904, -4.635, 4.635, 13.904, 23.174],
+             [-19.942, -11.965, -3.988, 3.988, 11.965, 19.942], [-16.065, -5.355, 5.355, 16.065],
+             [-14.317, -4.772, 4.772, 14.317], [-12.972, -4.324, 4.324, 12.972], [-11.756, -3.919, 3.919, 11.756],
+             [-10.791, -3.597, 3.597, 10.791]]                               # module azimuths, sector.py:402-410
+ARCUS_RIN = [320.443, 382.638, 444.833, 507.027, 569.222, 631.417, 693.612, 755.807]   # sector.py:413
+ARCUS_ROUT = [376.243, 438.438, 500.633, 562.827, 625.022, 681.217, 749.412, 811.607]  # sector.py:414
+ARCUS_SPAN = [50.159, 49.839, 49.614, 89.363, 82.476, 77.572, 86.892, 82.053]          # sector.py:417
+
+
+def arcus_shells(F=12e3, pitch=.775):
+    """(r0, z0, module angle [rad], azimuthal width [rad]) for every shell of every module."""
+    out = []
+    for i in range(8):
+        for a in ARCUS_ANG[i]:
+            for r0 in np.arange(ARCUS_RIN[i], ARCUS_ROUT[i], pitch):
+                out.append((float(r0), math.sqrt(F * F - r0 * r0), a * math.pi / 180, ARCUS_SPAN[i] / r0))
+    return out
+
+
+def config5(n, reps, lmir=50.):
+    """One GPU's share of config 5: `n` rays spread evenly over all 2.7k shells of the Arcus layout,
+    each shell with its own Wolter-I prescription (r0, z0=sqrt(F^2-r0^2)).  Per shell: device source
+    into the shell's slice of ONE big bundle, then the two-bounce chain as a fused program on that
+    slice (1 launch); then the grating stage + focal plane as one program over the whole bundle.
+    The ~5.5k launches are captured once in a HIP graph and replayed (launch-bound otherwise)."""
+    shells = arcus_shells()
+    ns = len(shells)
+    per = max(2, (n // ns) // 2 * 2)                # even -> every slice stays 16-byte aligned
+    n = per * ns
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((10, n), dtype=torch.float64, device=dev)
+    rays = [buf[i] for i in range(10)]
+    geo = [(r0, z0, a, w, float(con.primrad(z0, r0, z0)), float(con.primrad(z0 + lmir, r0, z0)))
+           for (r0, z0, a, w) in shells]
+    ty, rx = -ZG * math.sin(GRAZE), math.pi / 2 - GRAZE
+
+    def step(seed):
+        for k, (r0, z0, a, w, rin, rout) in enumerate(geo):
+            sl = [c[k * per:(k + 1) * per] for c in rays]
+            sources.subannulus(rin, rout, w, per, zhat=-1., rng="philox", seed=seed, first_index=k * per, out=sl)
+            with pxf.fused():
+                tran.transform(sl, 0, 0, -(z0 + 2 * lmir), 0, 0, a)      # to the shell's focus frame, module azimuth
+                surf.wolterprimary(sl, r0, z0)
+                tran.reflect(sl)
+                surf.woltersecondary(sl, r0, z0)
+                tran.reflect(sl)
+        with pxf.fused():                                                  # grating stage on the whole bundle
+            tran.transform(rays, 0, ty, 0, rx, 0, 0)
+            surf.flat(rays)
+            tran.reflect(rays)
+            tran.radgrat(rays, 160. / ZG, 1., 2.4)
+            tran.itransform(rays, 0, ty, 0, rx, 0, 0)
+            surf.flat(rays)
+
+    res = {"config": 5, "rays": n, "shells": ns, "rays_per_shell": per}
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    step(50)                                                               # warm-up, eager
+    torch.cuda.synchronize()
+    import time
+    best = None
+    for r in range(reps):
+        t0 = time.perf_counter()
+        a.record(); step(51 + r); b.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3
+        best = wall if best is None else min(best, wall)
+    res["eager_loop"] = {"ms_wall": best, "rays_per_s": n / (best * 1e-3), "launches": 2 * ns + 1}
+    res["valid_fraction"] = float(torch.isfinite(rays[6]).double().mean())
+    res["focal_rms_x_mm"], res["focal_rms_y_mm"] = anal.rmsX(rays), anal.rmsY(rays)
+    ref_x = rays[1].clone()
+    # the same step as one captured HIP graph
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            step(51 + reps - 1)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gbest = None
+    for r in range(reps + 1):
+        a.record(); g.replay(); b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b)
+        if r > 0:
+            gbest = ms if gbest is None else min(gbest, ms)
+    res["hip_graph"] = {"ms": gbest, "rays_per_s": n / (gbest * 1e-3), "nodes": 2 * ns + 1}
+    res["graph_equals_eager"] = bool(torch.equal(torch.nan_to_num(rays[1]), torch.nan_to_num(ref_x)))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=float, default=1e8)
@@ -150,7 +242,7 @@ def main():
     n = int(args.rays)
     torch.cuda.set_device(0)
     for c in args.configs.split(","):
-        res = config3(n, args.reps) if c == "3" else config4(n, args.reps)
+        res = {"3": config3, "4": config4, "5": config5}[c](n, args.reps)
         print(json.dumps(res), flush=True)
 
 
