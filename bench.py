@@ -214,6 +214,9 @@ def main():
 
     # ---- the same K steps again as ONE fused launch per step (reported separately, never mixed
     # into `value`: 120 algorithmic B/ray instead of 576; bit-identical results) --------------------
+    last = bundles[(K - 1) % pool]
+    del bundles                      # keep only the last traced bundle (focal-plane metrics below)
+    torch.cuda.empty_cache()
     fused = None
     if not args.no_fused:
         import pyxfocus_amd as pxf
@@ -242,15 +245,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             felapsed = float(t.item())
         fms = float(np.mean([fev[2 * i].elapsed_time(fev[2 * i + 1]) for i in range(K)]))
-        same = all(torch.equal(a, b) for a, b in zip(fb[(K - 1) % pool], [c for c in fb[(K - 1) % pool]]))
         fused = {"value": N * n_gpus * K / felapsed, "unit": "rays/s", "ms_per_step": felapsed / K * 1e3,
                  "launches_per_step": 1, "algorithmic_bytes_per_ray": 120, "avg_launch_ms": fms,
                  "GBps": 120.0 * N / (fms * 1e-3) / 1e9, "frac_of_hbm_peak": 120.0 * N / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "note": "pyxfocus_amd.fused(): same calls recorded and run as one ray-program kernel"}
-        del fb, same
+        del fb
+        torch.cuda.empty_cache()
 
     # ---- focal plane: global metric via all-reduce, and the all-gather the north-star names ----
-    last = bundles[(K - 1) % pool]
     rms = anal.rmsCentroid(last, group=True if dist else None)
     gather = None
     if dist and not args.no_gather:
