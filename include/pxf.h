@@ -118,6 +118,41 @@ int pxf_woltersecondary(double *x, double *y, double *z, const double *l, const 
 int pxf_spocone(double *x, double *y, double *z, double *l, double *m, double *n, double *ux, double *uy,
                 double *uz, int64_t num, double R0, double tg, const uint8_t *mask, pxf_stream_t stream);
 
+/* woltersine(x,...,uz,num,r0,z0,amp,freq)   woltsurf.f95:167-215   (primary with a sinusoidal axial ripple) */
+int pxf_woltersine(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                   double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double amp,
+                   double freq, const uint8_t *mask, pxf_stream_t stream);
+
+/* Legendre-Legendre deformed mirrors.  coeff/axial/az are HOST arrays of length cnum (folded on the
+ * host into a dense (axial x az) matrix that the kernel stages in LDS; PXF_ERANGE if that matrix
+ * would exceed 256 entries).
+ * wolterprimLL(x,...,uz,num,r0,z0,zmax,zmin,dphi,coeff,axial,az,cnum)          woltsurf.f95:220-288
+ * woltersecLL(x,...,uz,num,r0,z0,psi,zmax,zmin,dphi,coeff,axial,az,cnum)       woltsurf.f95:293-379
+ * ellipsoidWoltLL(x,...,uz,num,r0,z0,psi,S,zmax,zmin,dphi,coeff,axial,az,cnum) woltsurf.f95:643-718 */
+int pxf_wolterprimll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double zmax,
+                     double zmin, double dphi, const double *coeff, const int32_t *axial, const int32_t *az,
+                     int32_t cnum, const uint8_t *mask, pxf_stream_t stream);
+int pxf_woltersecll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                    double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double psi,
+                    double zmax, double zmin, double dphi, const double *coeff, const int32_t *axial,
+                    const int32_t *az, int32_t cnum, const uint8_t *mask, pxf_stream_t stream);
+int pxf_ellipsoidwoltll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                        double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double psi,
+                        double S, double zmax, double zmin, double dphi, const double *coeff,
+                        const int32_t *axial, const int32_t *az, int32_t cnum, const uint8_t *mask,
+                        pxf_stream_t stream);
+
+/* wsprimary / wssecondary (x,...,uz,num,alpha,z0,psi)   woltsurf.f95:387-476 / 484-588
+ * Wolter-Schwarzschild pair; 26-iteration cap: a ray that does not converge gets its start
+ * position back and keeps its previous normal (callers vignette on "did not move"). */
+int pxf_wsprimary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                  double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                  const uint8_t *mask, pxf_stream_t stream);
+int pxf_wssecondary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                    double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                    const uint8_t *mask, pxf_stream_t stream);
+
 /* ---- zernsurf.f95 (+ zernset, specialFunctions.f95:142-232) ------------------------------- */
 
 /* tracezern(x,...,uz,num,coeff,rorder,aorder,arrsize,rad)   zernsurf.f95:8-101

@@ -94,6 +94,13 @@ def load_port(omp=False):
     f_cc = sig("orc_cylconic", *[P] * 9, i64, d, d)
     f_px = sig("orc_paraxial", *[P] * 4, i64, d, C.c_int)
     f_rf = sig("orc_refract", *[P] * 6, i64, d, d)
+    f_wsin = sig("orc_woltersine", *[P] * 9, i64, d, d, d, d)
+    f_pll = sig("orc_wolterprimll", *[P] * 9, i64, d, d, d, d, d, P, _ip, _ip, i32)
+    f_sll = sig("orc_woltersecll", *[P] * 9, i64, d, d, d, d, d, d, P, _ip, _ip, i32)
+    f_ell = sig("orc_ellipsoidwoltll", *[P] * 9, i64, d, d, d, d, d, d, d, P, _ip, _ip, i32)
+    f_wsp = sig("orc_wsprimary", *[P] * 9, i64, d, d, d)
+    f_wss = sig("orc_wssecondary", *[P] * 9, i64, d, d, d)
+    f_leg = sig("orc_legendre", d, i32, P, P)
 
     def flat(x, y, z, l, m, n, ux, uy, uz):
         p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
@@ -208,6 +215,44 @@ def load_port(omp=False):
         p, num = _cols(l, m, n, ux, uy, uz)
         f_rf(*p, num, n1, n2)
 
+    def woltersine(x, y, z, l, m, n, ux, uy, uz, r0, z0, amp, freq):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_wsin(*p, num, r0, z0, amp, freq)
+
+    def _ll(coeff, axial, az):
+        ck, cp = _f64in(coeff)
+        ak, ap = _i32(axial)
+        zk, zp = _i32(az)
+        return (ck, ak, zk), (cp, ap, zp, len(ck))
+
+    def wolterprimll(x, y, z, l, m, n, ux, uy, uz, r0, z0, zmax, zmin, dphi, coeff, axial, az):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        keep, t = _ll(coeff, axial, az)
+        f_pll(*p, num, r0, z0, zmax, zmin, dphi, *t)
+
+    def woltersecll(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, zmax, zmin, dphi, coeff, axial, az):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        keep, t = _ll(coeff, axial, az)
+        f_sll(*p, num, r0, z0, psi, zmax, zmin, dphi, *t)
+
+    def ellipsoidwoltll(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, S, zmax, zmin, dphi, coeff, axial, az):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        keep, t = _ll(coeff, axial, az)
+        f_ell(*p, num, r0, z0, psi, S, zmax, zmin, dphi, *t)
+
+    def wsprimary(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_wsp(*p, num, alpha, z0, psi)
+
+    def wssecondary(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_wss(*p, num, alpha, z0, psi)
+
+    def legendre(x, n):
+        a, b = C.c_double(), C.c_double()
+        f_leg(x, n, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def wolter_params(r0, z0, psi=1.):
         o = [C.c_double() for _ in range(3)]
         f_par(r0, z0, psi, *[C.byref(v) for v in o])
@@ -220,7 +265,10 @@ def load_port(omp=False):
                                   tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial,
                                   paraxialy=paraxialy),
         woltsurf=SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
-                                 woltersecondary=woltersecondary, spocone=spocone),
+                                 woltersecondary=woltersecondary, spocone=spocone, woltersine=woltersine,
+                                 wolterprimll=wolterprimll, woltersecll=woltersecll,
+                                 ellipsoidwoltll=ellipsoidwoltll, wsprimary=wsprimary, wssecondary=wssecondary,
+                                 legendre=legendre),
         zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
         transformationsf=SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
                                          radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract),
@@ -321,6 +369,26 @@ def load_ref(omp=False):
         p, num = _cols(x, y, l, m, n, wave)
         f_rgw(*p, num32(num), dref(dpermm), dref(order))
 
+    def mkll(name, nscal):
+        f = fn("woltsurf", name)
+
+        def call(x, y, z, l, m, n, ux, uy, uz, *args):
+            scal, (coeff, axial, az) = args[:nscal], args[nscal:]
+            p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+            ck, cp = _f64in(coeff)
+            ak, ap = _i32(axial)
+            zk, zp = _i32(az)
+            f(*p, num32(num), *[dref(v) for v in scal], cp, ap, zp, C.byref(C.c_int32(len(ck))))
+        return call
+
+    f_leg = getattr(L["woltsurf"], "legendre_")
+    f_leg.restype = C.c_double
+    f_legp = getattr(L["woltsurf"], "legendrep_")
+    f_legp.restype = C.c_double
+
+    def legendre(x, n):
+        return (f_leg(dref(x), C.byref(C.c_int32(n))), f_legp(dref(x), C.byref(C.c_int32(n))))
+
     f_gr = fn("transformationsf", "grat")
 
     def grat(x, y, l, m, n, d_, order, wave):
@@ -350,7 +418,12 @@ def load_ref(omp=False):
         woltsurf=SimpleNamespace(wolterprimary=mk9("woltsurf", "wolterprimary", 3),
                                  wolterprimaryopd=mk10("woltsurf", "wolterprimaryopd", 4),
                                  woltersecondary=mk9("woltsurf", "woltersecondary", 3),
-                                 spocone=mk9("woltsurf", "spocone", 2)),
+                                 spocone=mk9("woltsurf", "spocone", 2),
+                                 woltersine=mk9("woltsurf", "woltersine", 4),
+                                 wolterprimll=mkll("wolterprimll", 5), woltersecll=mkll("woltersecll", 6),
+                                 ellipsoidwoltll=mkll("ellipsoidwoltll", 7),
+                                 wsprimary=mk9("woltsurf", "wsprimary", 3),
+                                 wssecondary=mk9("woltsurf", "wssecondary", 3), legendre=legendre),
         zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
         transformationsf=SimpleNamespace(transform=mk9("transformationsf", "transform", 6),
                                          itransform=mk9("transformationsf", "itransform", 6),

@@ -42,6 +42,12 @@ SIG = {
     "surfacesf.paraxial": "x y z l m n ux uy uz",
     "surfacesf.paraxialy": "x y z l m n ux uy uz",
     "transformationsf.refract": "l m n ux uy uz",
+    "woltsurf.woltersine": "x y z l m n ux uy uz",
+    "woltsurf.wolterprimll": "x y z l m n ux uy uz",
+    "woltsurf.woltersecll": "x y z l m n ux uy uz",
+    "woltsurf.ellipsoidwoltll": "x y z l m n ux uy uz",
+    "woltsurf.wsprimary": "x y z l m n ux uy uz",
+    "woltsurf.wssecondary": "x y z l m n ux uy uz",
 }
 ALLCOLS = "opd x y z l m n ux uy uz".split()
 
@@ -279,6 +285,45 @@ def cases(num=2048, seed=1234):
     out.append(("refract_in", "transformationsf.refract", c, (1., 1.5)))
     c2 = {kk: v.copy() for kk, v in c.items()}
     out.append(("refract_out", "transformationsf.refract", c2, (1.5, 1.)))   # incl. total internal reflection -> NaN
+
+    # ================= widening batch 2 (appended) ================================================
+    # ---- sinusoidally perturbed primary ------------------------------------------------------------
+    out.append(("woltersine", "woltsurf.woltersine", primary_input(rng, num, offaxis=1e-4), (R0, Z0, 1e-4, 1. / 20.)))
+
+    # ---- Legendre-Legendre deformed primary / secondary / ellipsoid primary (sub-aperture) ------------
+    def sub_input(psi, off=0.):
+        rin, rout = primrad(Z0, R0, Z0, psi), primrad(Z0 + LMIR, R0, Z0, psi)
+        rho = np.sqrt(rin ** 2 + rng.random(num) * (rout ** 2 - rin ** 2))
+        th = rng.random(num) * .5 - .25
+        zero = np.zeros(num)
+        return dict(opd=zero.copy(), x=rho * np.cos(th), y=rho * np.sin(th), z=np.full(num, Z0 + 2 * LMIR),
+                    l=np.full(num, math.sin(off)), m=zero.copy(), n=np.full(num, -math.sqrt(1 - math.sin(off) ** 2)),
+                    ux=zero.copy(), uy=zero.copy(), uz=zero.copy())
+    llc = np.array([2e-4, -1e-4, 5e-5, 3e-5, -2e-5, 1e-5])
+    lax = np.array([0, 1, 2, 0, 3, 5], dtype=np.int32)
+    laz = np.array([0, 0, 1, 2, 2, 4], dtype=np.int32)
+    c = sub_input(PSI, off=2e-4)
+    out.append(("wolterprimll", "woltsurf.wolterprimll", c, (R0, Z0, Z0 + LMIR, Z0, .6, llc, lax, laz)))
+    c2 = {kk: v.copy() for kk, v in c.items()}
+    a = [c2[kk] for kk in "x y z l m n ux uy uz".split()]
+    port.woltsurf.wolterprimary(*a, R0, Z0, PSI)
+    port.transformationsf.reflect(*a[3:])
+    out.append(("woltersecll", "woltsurf.woltersecll", c2, (R0, Z0, PSI, Z0 - 10., Z0 - 10. - LMIR, .6, llc, lax, laz)))
+    S_ = 1e5
+    out.append(("ellipsoidwoltll", "woltsurf.ellipsoidwoltll", sub_input(PSI),
+                (R0, Z0, PSI, S_, Z0 + LMIR, Z0, .6, llc, lax, laz)))
+
+    # ---- Wolter-Schwarzschild primary / secondary (Chase parameters from alpha = atan(r0/z0)/4) ---------
+    alpha = .25 * math.atan(R0 / Z0)
+    c = primary_input(rng, num, offaxis=1e-4)
+    c["x"][:4] *= .9                      # inside the inner radius: the beta <= betas branch
+    c["x"][4] = c["y"][4] = 0.            # on the axis -> NaN -> position restored
+    out.append(("wsprimary", "woltsurf.wsprimary", c, (alpha, Z0, PSI)))
+    c2 = {kk: v.copy() for kk, v in primary_input(rng, num).items()}
+    a = [c2[kk] for kk in "x y z l m n ux uy uz".split()]
+    port.woltsurf.wsprimary(*a, alpha, Z0, PSI)
+    port.transformationsf.reflect(*a[3:])
+    out.append(("wssecondary", "woltsurf.wssecondary", c2, (alpha, Z0, PSI)))
     return out
 
 

@@ -725,3 +725,354 @@ void orc_refract(double *l, double *m, double *n, double *ux, double *uy, double
         n[i] = n[i] / alpha;
     }
 }
+
+/* ==================================================================================== */
+/* Widening batch 2: sinusoidally perturbed primary, Legendre-Legendre
+ * deformed Wolter / ellipsoid mirrors, Wolter-Schwarzschild primary and secondary.        */
+
+/* x**k with a run-time INTEGER exponent: binary exponentiation, as compiler-rt's __powidf2
+ * (what the flang-compiled reference calls for integer powers). */
+static double powi(double a, int b)
+{
+    const int recip = b < 0;
+    double r = 1;
+    while (1) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1 / r : r;
+}
+
+static double ipow_int(int base, int e) /* integer ** integer (e >= 0), as Fortran */
+{
+    long long r = 1;
+    for (int i = 0; i < e; i++) r *= base;
+    return (double)(int)r;
+}
+
+static double factorial_d(int n) /* specialFunctions.f95:2-14 */
+{
+    double a = 1;
+    for (int i = 1; i <= n; i++) a = a * (double)i;
+    return a;
+}
+
+/* specialFunctions.f95:337-360 */
+static double legendre(double x, int n)
+{
+    double x2 = fabs(x) > 1. ? x / fabs(x) : x;
+    double s = 0.;
+    if (n == 0) return 1.;
+    for (int i = 0; i <= n / 2; i++)
+        s = s + ipow_int(-1, i) * factorial_d(2 * n - 2 * i) / factorial_d(i) / factorial_d(n - i) /
+                    factorial_d(n - 2 * i) / ipow_int(2, n) * powi(x2, n - 2 * i);
+    return s;
+}
+
+/* specialFunctions.f95:363-388 */
+static double legendrep(double x, int n)
+{
+    double s = 0.;
+    if (n == 0)
+        s = 0.;
+    else if (n == 1)
+        s = 1.;
+    else if (x == 0. && n % 2 == 0)
+        s = 0.;
+    else
+        for (int i = 0; i <= n / 2; i++)
+            s = s + ipow_int(-1, i) * factorial_d(2 * n - 2 * i) / factorial_d(i) / factorial_d(n - i) /
+                        factorial_d(n - 2 * i) / ipow_int(2, n) * (n - 2 * i) * powi(x, n - 2 * i - 1);
+    if (fabs(x) > 1.) s = 0.;
+    return s;
+}
+
+void orc_legendre(double x, int32_t n, double *p, double *dp)
+{
+    *p = legendre(x, n);
+    *dp = legendrep(x, n);
+}
+
+/* woltsurf.f95:167-215 */
+void orc_woltersine(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                    double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double amp,
+                    double freq)
+{
+    double alpha = .25 * atan(r0 / z0);
+    double thetah = 3. * alpha, thetap = alpha;
+    double p = z0 * tan(4 * alpha) * tan(thetap);
+    double d = z0 * tan(4 * alpha) * tan(4 * alpha - thetah);
+    double e = cos(4 * alpha) * (1 + tan(4 * alpha) * tan(thetah));
+    const double pi32 = (double)acosf(-1.f);
+    const double twopi32 = (double)(2.f * acosf(-1.f)); /* 2*acos(-1.) is a REAL*4 product */
+    for (int64_t i = 0; i < num; i++) {
+        double delt = 100., Fx = 0., Fy = 0., Fz = 0., Fp;
+        int it = 0;
+        while (fabs(delt) > TOL_1EM10 && it < ORC_NEWTON_CAP) {
+            double rad = sqrt(x[i] * x[i] + y[i] * y[i]) + amp * sin(twopi32 * freq * z[i]);
+            double F = 2 * p * z[i] + p * p + 4 * (e * e) * p * d / (e * e - 1) - rad * rad;
+            Fx = -2. * x[i];
+            Fy = -2. * y[i];
+            Fz = 2. * p - 2 * rad * amp * 2 * pi32 * freq * cos(twopi32 * freq * z[i]);
+            Fp = Fx * l[i] + Fy * m[i] + Fz * n[i];
+            delt = -F / Fp;
+            x[i] = x[i] + l[i] * delt;
+            y[i] = y[i] + m[i] * delt;
+            z[i] = z[i] + n[i] * delt;
+            it++;
+        }
+        Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+        ux[i] = Fx / Fp;
+        uy[i] = Fy / Fp;
+        uz[i] = Fz / Fp;
+    }
+}
+
+/* Shared body of wolterprimLL (woltsurf.f95:220-288), woltersecLL (:293-379) and
+ * ellipsoidWoltLL (:643-718).  kind: 0 primary, 1 secondary, 2 ellipsoid. */
+static void ll_core(int kind, double *x, double *y, double *z, const double *l, const double *m,
+                    const double *n, double *ux, double *uy, double *uz, int64_t num, double p, double d,
+                    double e, double aa, double bb, double zfoc, double tol, double zmax, double zmin,
+                    double dphi, const double *coeff, const int32_t *axial, const int32_t *az, int cnum)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double delt = 100., Fx = 0., Fy = 0., Fz = 0., Fp, F;
+        int it = 0;
+        while (fabs(delt) > tol && it < ORC_NEWTON_CAP) {
+            double ang = atan2(y[i], x[i]);
+            double zarg = (z[i] - ((zmax + zmin) / 2.)) / ((zmax - zmin) / 2.);
+            double targ = 2 * ang / dphi;
+            double add = 0., addx = 0., addy = 0., addz = 0.;
+            for (int a = 0; a < cnum; a++) {
+                add = add + coeff[a] * legendre(zarg, axial[a]) * legendre(targ, az[a]);
+                addx = addx - coeff[a] * legendre(zarg, axial[a]) * legendrep(targ, az[a]) * (2 / dphi) *
+                                  (y[i] / (y[i] * y[i] + x[i] * x[i]));
+                addy = addy + coeff[a] * legendre(zarg, axial[a]) * legendrep(targ, az[a]) * (2 / dphi) *
+                                  (x[i] / (y[i] * y[i] + x[i] * x[i]));
+                addz = addz + coeff[a] * legendrep(zarg, axial[a]) * legendre(targ, az[a]) * 2 / (zmax - zmin);
+            }
+            double rr = sqrt(x[i] * x[i] + y[i] * y[i]);
+            double G = rr + add;
+            if (kind == 0) {
+                F = -(G * G - p * p - 2 * p * z[i] - 4 * (e * e) * p * d / (e * e - 1));
+                Fx = -(2 * G * (x[i] / rr + addx));
+                Fy = -(2 * G * (y[i] / rr + addy));
+                Fz = 2 * p - 2 * G * addz;
+            } else if (kind == 1) {
+                double dz = d + z[i];
+                F = -(G * G - (e * e) * (dz * dz) + z[i] * z[i]);
+                Fx = -(2 * G * (x[i] / rr + addx));
+                Fy = -(2 * G * (y[i] / rr + addy));
+                Fz = 2 * (e * e) * dz - 2 * z[i] - 2 * G * addz;
+            } else {
+                double zz = z[i] - zfoc;
+                F = zz * zz / (aa * aa) + G * G / (bb * bb) - 1.;
+                Fx = 2 * G / (bb * bb) * (x[i] / rr + addx);
+                Fy = 2 * G / (bb * bb) * (y[i] / rr + addy);
+                Fz = 2 * zz / (aa * aa) + (2 * G / (bb * bb)) * (addz);
+            }
+            Fp = Fx * l[i] + Fy * m[i] + Fz * n[i];
+            delt = -F / Fp;
+            x[i] = x[i] + l[i] * delt;
+            y[i] = y[i] + m[i] * delt;
+            z[i] = z[i] + n[i] * delt;
+            it++;
+        }
+        Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+        ux[i] = Fx / Fp;
+        uy[i] = Fy / Fp;
+        uz[i] = Fz / Fp;
+    }
+}
+
+void orc_wolterprimll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                      double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double zmax,
+                      double zmin, double dphi, const double *coeff, const int32_t *axial,
+                      const int32_t *az, int32_t cnum)
+{
+    double alpha = .25 * atan(r0 / z0);
+    double thetah = 3. * alpha, thetap = alpha;
+    double p = z0 * tan(4 * alpha) * tan(thetap);
+    double d = z0 * tan(4 * alpha) * tan(4 * alpha - thetah);
+    double e = cos(4 * alpha) * (1 + tan(4 * alpha) * tan(thetah));
+    ll_core(0, x, y, z, l, m, n, ux, uy, uz, num, p, d, e, 0., 0., 0., TOL_1EM10, zmax, zmin, dphi, coeff,
+            axial, az, cnum);
+}
+
+void orc_woltersecll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double psi,
+                     double zmax, double zmin, double dphi, const double *coeff, const int32_t *axial,
+                     const int32_t *az, int32_t cnum)
+{
+    double p, d, e;
+    orc_wolter_params(r0, z0, psi, &p, &d, &e);
+    ll_core(1, x, y, z, l, m, n, ux, uy, uz, num, p, d, e, 0., 0., 0., (double)1.e-7f, zmax, zmin, dphi,
+            coeff, axial, az, cnum);
+}
+
+void orc_ellipsoid_params(double R0, double z0, double psi, double S, double *aa, double *bb, double *zfoc)
+{
+    double P = R0 / sin((psi * asin(R0 / z0) - asin(R0 / S)) / (1 + psi));
+    double ff = (S + P) / 2.;
+    double bq = -(R0 * R0 + (ff - P) * (ff - P) + ff * ff);
+    double cq = ff * ff * ((ff - P) * (ff - P));
+    *aa = sqrt((-bq + sqrt(bq * bq - 4 * cq)) / 2.);
+    *bb = sqrt(*aa * *aa - ff * ff);
+    *zfoc = ff - P + z0;
+}
+
+void orc_ellipsoidwoltll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                         double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double psi,
+                         double S, double zmax, double zmin, double dphi, const double *coeff,
+                         const int32_t *axial, const int32_t *az, int32_t cnum)
+{
+    double aa, bb, zfoc;
+    orc_ellipsoid_params(r0, z0, psi, S, &aa, &bb, &zfoc);
+    ll_core(2, x, y, z, l, m, n, ux, uy, uz, num, 0., 0., 0., aa, bb, zfoc, TOL_1EM10, zmax, zmin, dphi, coeff,
+            axial, az, cnum);
+}
+
+/* woltsurf.f95:387-476.  26-iteration cap; a non-converged / NaN ray gets its start position
+ * back and keeps its old normal. */
+void orc_wsprimary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                   double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi)
+{
+    const double betas = 4 * alpha, ff = z0 / cos(betas), g = ff / psi;
+    const double tb = tan(betas / 2), k = tb * tb;
+    for (int64_t i = 0; i < num; i++) {
+        double delt = 100., F, Fx = 0., Fy = 0., Fz = 0., Fp, Fb, beta, kterm, r, dbdx, dbdy;
+        int c = 0, flag;
+        const double xi = x[i], yi = y[i], zi = z[i];
+        while (fabs(delt) > TOL_1EM8) {
+            beta = asin(sqrt(x[i] * x[i] + y[i] * y[i]) / ff);
+            flag = 0;
+            if (beta <= betas) {
+                beta = betas;
+                flag = 1;
+                kterm = 0.;
+            } else {
+                double t = tan(beta / 2);
+                kterm = (1 / k) * (t * t) - 1;
+            }
+            {
+                double sb2 = sin(betas / 2), sb = sin(beta), cb2 = cos(beta / 2);
+                F = -z[i] - ff * (sb2 * sb2) + ff * ff * (sb * sb) / (4 * ff * (sb2 * sb2)) +
+                    g * (((cb2 * cb2) * cb2) * cb2) * pow(kterm, 1 - k) /* x**4 with a literal exponent: sequential products */;
+                Fb = ff * ff * sb * cos(beta) / (2 * ff * (sb2 * sb2)) -
+                     2 * g * ((cb2 * cb2) * cb2) * sin(beta / 2) * pow(kterm, 1 - k) +
+                     g * (1 - k) * cb2 * sin(beta / 2) * pow(kterm, -k) * (1 / k);
+            }
+            Fz = -1.;
+            if (flag == 1) {
+                double sb2 = sin(betas / 2);
+                r = sqrt(x[i] * x[i] + y[i] * y[i]);
+                Fb = ff * ff * sin(betas) * cos(betas) / (2 * ff * (sb2 * sb2)) +
+                     g * (1 - k) * cos(betas / 2) * sin(betas / 2) * (1 / k);
+                F = F + (r - ff * sin(betas)) * z[i] / (r * r + z[i] * z[i]) * Fb;
+                Fz = Fz + (r - ff * sin(betas)) * (r * r - z[i] * z[i]) /
+                              ((r * r + z[i] * z[i]) * (r * r + z[i] * z[i])) * Fb;
+            }
+            {
+                double r2 = x[i] * x[i] + y[i] * y[i];
+                dbdx = x[i] / sqrt(1 - r2 / (ff * ff)) / ff / sqrt(r2);
+                dbdy = y[i] / sqrt(1 - r2 / (ff * ff)) / ff / sqrt(r2);
+            }
+            Fx = Fb * dbdx;
+            Fy = Fb * dbdy;
+            Fp = Fx * l[i] + Fy * m[i] + Fz * n[i];
+            delt = -F / Fp;
+            x[i] = x[i] + l[i] * delt;
+            y[i] = y[i] + m[i] * delt;
+            z[i] = z[i] + n[i] * delt;
+            if (c > 25 || isnan(delt)) {
+                delt = 0.;
+                x[i] = xi;
+                y[i] = yi;
+                z[i] = zi;
+                c = 1000;
+            }
+            c = c + 1;
+        }
+        if (c < 26) {
+            Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+            ux[i] = -Fx / Fp;
+            uy[i] = -Fy / Fp;
+            uz[i] = -Fz / Fp;
+        }
+    }
+}
+
+/* woltsurf.f95:484-588 */
+void orc_wssecondary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi)
+{
+    const double betas = 4 * alpha, ff = z0 / cos(betas), g = ff / psi;
+    const double tb = tan(betas / 2), k = tb * tb;
+    for (int64_t i = 0; i < num; i++) {
+        double delt = 100., F, Fx = 0., Fy = 0., Fz = 0., Fp, Fb, beta, kterm, a, dadb, dbdx, dbdy, dbdz;
+        int c = 0, flag;
+        const double xi = x[i], yi = y[i], zi = z[i];
+        while (fabs(delt) > TOL_1EM8) {
+            double rr = sqrt(x[i] * x[i] + y[i] * y[i]);
+            beta = atan2(rr, z[i]);
+            flag = 0;
+            if (beta <= betas) {
+                beta = betas;
+                kterm = 0;
+                a = 1 / ff;
+                flag = 1;
+            } else {
+                double t = tan(beta / 2);
+                kterm = (1 / k) * (t * t) - 1;
+                a = (1 - cos(beta)) / (1 - cos(betas)) / ff + (1 + cos(beta)) / (2 * g) * pow(kterm, 1 + k);
+            }
+            F = -z[i] + cos(beta) / a;
+            if (flag == 1) {
+                double cb2 = cos(betas / 2);
+                double dadbs = sin(betas) / ff / (1 - cos(betas)) +
+                               (k + 1) * (cos(betas) + 1) * tan(betas / 2) / (cb2 * cb2) / 2 / g / k;
+                double sbs = sin(betas);
+                double dbdzs = -(sbs * sbs) / rr;
+                double gam = (-ff * sin(betas) - ff * ff * cos(betas) * dadbs) * dbdzs;
+                Fb = 0.;
+                F = F + gam * (z[i] - rr / tan(betas));
+                Fx = -2. / tan(betas) * x[i] / rr;
+                Fy = -2. / tan(betas) * y[i] / rr;
+                Fz = gam - 1.;
+            } else {
+                double cb2 = cos(beta / 2);
+                double r3 = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
+                dadb = sin(beta) / ff / (1 - cos(betas)) - sin(beta) / (2 * g) * pow(kterm, 1 + k) +
+                       (k + 1) * (cos(beta) + 1) * tan(beta / 2) * pow(kterm, k) / 2 / g / k / (cb2 * cb2);
+                Fb = -sin(beta) / a - cos(beta) / (a * a) * dadb;
+                dbdx = x[i] * z[i] / r3 / rr;
+                dbdy = y[i] * z[i] / r3 / rr;
+                dbdz = -rr / r3;
+                Fx = Fb * dbdx;
+                Fy = Fb * dbdy;
+                Fz = -1. + Fb * dbdz;
+            }
+            Fp = Fx * l[i] + Fy * m[i] + Fz * n[i];
+            delt = -F / Fp;
+            x[i] = x[i] + l[i] * delt;
+            y[i] = y[i] + m[i] * delt;
+            z[i] = z[i] + n[i] * delt;
+            if (c > 25 || isnan(delt)) {
+                delt = 0.;
+                x[i] = xi;
+                y[i] = yi;
+                z[i] = zi;
+                c = 1000;
+            }
+            c = c + 1;
+        }
+        if (c < 26) {
+            Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+            ux[i] = Fx / Fp;
+            uy[i] = Fy / Fp;
+            uz[i] = Fz / Fp;
+        }
+    }
+}

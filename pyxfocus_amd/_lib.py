@@ -37,6 +37,12 @@ _SIGS = {
     "pxf_cylconic": [_P] * 9 + [_i64, _d, _d, _P, _P],
     "pxf_paraxial": [_P] * 4 + [_i64, _d, _P, _P],
     "pxf_paraxialy": [_P] * 2 + [_i64, _d, _P, _P],
+    "pxf_woltersine": [_P] * 9 + [_i64, _d, _d, _d, _d, _P, _P],
+    "pxf_wolterprimll": [_P] * 9 + [_i64] + [_d] * 5 + [_DP, _IP, _IP, _i32, _P, _P],
+    "pxf_woltersecll": [_P] * 9 + [_i64] + [_d] * 6 + [_DP, _IP, _IP, _i32, _P, _P],
+    "pxf_ellipsoidwoltll": [_P] * 9 + [_i64] + [_d] * 7 + [_DP, _IP, _IP, _i32, _P, _P],
+    "pxf_wsprimary": [_P] * 9 + [_i64, _d, _d, _d, _P, _P],
+    "pxf_wssecondary": [_P] * 9 + [_i64, _d, _d, _d, _P, _P],
     "pxf_spocone": [_P] * 9 + [_i64, _d, _d, _P, _P],
     "pxf_grat": [_P] * 3 + [_i64, _d, _d, _P, _P, _P],
     "pxf_refract": [_P] * 6 + [_i64, _d, _d, _P, _P],

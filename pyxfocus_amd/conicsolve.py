@@ -40,3 +40,17 @@ def primfocus(r0, z0):
     """Distance to the primary focus."""
     alpha, p, d, e = woltparam(r0, z0)
     return z0 + 2 * e ** 2 * d / (e ** 2 - 1)
+
+
+def ellipsoidFunction(S, psi, R, F):
+    """Ellipsoid-hyperboloid telescope: primary focal length P and ellipsoid a, b, e, f
+    (conicsolve.py:263-281)."""
+    P = R / np.sin((psi * np.arcsin(R / F) - np.arcsin(R / S)) / (1 + psi))
+    f = (S + P) / 2.
+    a = 1.
+    b = -(R ** 2 + (f - P) ** 2 + f ** 2)
+    c = f ** 2 * (f - P) ** 2
+    a = np.sqrt((-b + np.sqrt(b ** 2 - 4 * a * c)) / (2 * a))
+    b = np.sqrt(a ** 2 - f ** 2)
+    e = f / a
+    return P, a, b, e, f

@@ -1,0 +1,432 @@
+// pxf_wolter2.hip -- widening batch 2: woltersine, the Legendre-Legendre
+// deformed mirrors (wolterprimLL, woltersecLL, ellipsoidWoltLL) and the Wolter-Schwarzschild
+// primary / secondary.  Reference: woltsurf.f95:167-215, 220-379, 643-718, 387-588 and
+// legendre/legendrep, specialFunctions.f95:337-388.
+//
+// These surfaces need per-ray transcendentals (atan2, sin/cos, asin, tan, pow), which come from
+// ocml here and glibc in the reference: parity is to a stated tolerance (tests/util.py), not
+// bitwise; the Newton iterations contract the differences.  Structure follows the reference's
+// loops exactly, including tolerances (1.e-10 / 1.e-7 / 1.e-8 as fp32 literals), the
+// stale-gradient normals, and the W-S 26-iteration cap that restores the start position.
+//
+// Legendre-Legendre: the reference evaluates every P_n by an explicit factorial sum, twice per
+// coefficient per Newton step.  Here the (coeff, axial, az) list is folded on the host into a
+// dense matrix C[axial][az], passed by value in the kernel arguments and staged in LDS; P_n and
+// P'_n come from the three-term recurrences, generated on the fly inside the double loop over
+// (axial, az) so no per-thread array is ever indexed at run time.
+#include <math.h>
+
+#include "pxf_kernel.h"
+
+namespace pxf {
+
+// ---- woltersine : woltsurf.f95:167-215 --------------------------------------------------------
+struct WolterSineOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = POS | DIR;
+    static constexpr unsigned WR = POS | NRM;
+    double twop, pp, cst, amp, freq, pi32, twopi32;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            double *c = r[k].c;
+            double Fx = 0., Fy = 0., Fz = 0.;
+            bool act = sel[k];
+            for (int it = 0; act && it < kNewtonCap; it++) {
+                const double x = c[X], y = c[Y], z = c[Z];
+                double sn, cs;
+                sincos(twopi32 * freq * z, &sn, &cs);
+                const double rad = sqrt(x * x + y * y) + amp * sn;
+                const double F = twop * z + pp + cst - rad * rad;
+                Fx = -2. * x;
+                Fy = -2. * y;
+                Fz = twop - 2 * rad * amp * 2 * pi32 * freq * cs;
+                const double Fp = Fx * c[L] + Fy * c[M] + Fz * c[N];
+                const double delt = -F / Fp;
+                c[X] = x + c[L] * delt;
+                c[Y] = y + c[M] * delt;
+                c[Z] = z + c[N] * delt;
+                act = fabs(delt) > PXF_TOL_1EM10;
+            }
+            const double Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+            c[UX] = Fx / Fp;
+            c[UY] = Fy / Fp;
+            c[UZ] = Fz / Fp;
+            wm[k] = WR;
+        }
+    }
+};
+
+// ---- Legendre-Legendre deformed mirrors --------------------------------------------------------
+constexpr int kLLMax = 256;  // (max axial + 1) * (max az + 1)
+
+template <int KIND>  // 0 primary (:220-288), 1 secondary (:293-379), 2 ellipsoid (:643-718)
+struct LLOp {
+    static constexpr int MAXV = 1;
+    static constexpr unsigned RD = POS | DIR;
+    static constexpr unsigned WR = POS | NRM;
+    double twop, pp, cst;    // primary
+    double e2, twoe2, d;     // secondary
+    double aa2, bb2, zfoc;   // ellipsoid: aa**2, bb**2
+    double tol, zmid, zhalf, two_over_dphi, two_over_dz;  // (zmax+zmin)/2, (zmax-zmin)/2, 2/dphi, 2/(zmax-zmin) pieces
+    double dphi, zspan;      // dphi, zmax-zmin
+    int ka, kt;              // highest axial / azimuthal order present
+    double cmat[kLLMax];     // C[i*(kt+1)+j], by value in the kernel-argument segment
+
+    __device__ __forceinline__ double *lds() const
+    {
+        __shared__ double s_c[kLLMax];
+        return s_c;
+    }
+    __device__ __forceinline__ void prologue() const
+    {
+        double *s = lds();
+        const int nn = (ka + 1) * (kt + 1);
+        for (int i = threadIdx.x; i < nn; i += kBlock) s[i] = cmat[i];
+        __syncthreads();
+    }
+
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+        const double *__restrict__ cm = lds();
+        double *c = r[0].c;
+        double Fx = 0., Fy = 0., Fz = 0.;
+        bool act = sel[0];
+        for (int it = 0; act && it < kNewtonCap; it++) {
+            const double x = c[X], y = c[Y], z = c[Z];
+            const double ang = atan2(y, x);
+            const double zarg = (z - zmid) / zhalf;
+            const double targ = 2 * ang / dphi;
+            // legendre() clamps |x|>1 to sign(x); legendrep() returns 0 there (specialFunctions.f95:345-349,384-386)
+            const double zc = fabs(zarg) > 1. ? zarg / fabs(zarg) : zarg;
+            const double tc = fabs(targ) > 1. ? targ / fabs(targ) : targ;
+            const bool zin = !(fabs(zarg) > 1.), tin = !(fabs(targ) > 1.);
+            double add = 0., addt = 0., addzz = 0.;
+            double pz0 = 1., pz1 = zc, dz0 = 0., dz1 = 1.;  // P_i, P_{i+1}, P'_i, P'_{i+1} in zarg
+            for (int i = 0; i <= ka; i++) {
+                const double Pz = pz0, dPz = zin ? dz0 : 0.;
+                double pt0 = 1., pt1 = tc, dt0 = 0., dt1 = 1.;
+                double s0 = 0., s1 = 0.;  // sum_j C_ij P_j(t), sum_j C_ij P'_j(t)
+                for (int j = 0; j <= kt; j++) {
+                    const double cij = cm[i * (kt + 1) + j];
+                    s0 += cij * pt0;
+                    s1 += cij * (tin ? dt0 : 0.);
+                    const double pn = ((2 * j + 3) * tc * pt1 - (j + 1) * pt0) / (j + 2);  // P_{j+2}
+                    const double dn = dt0 + (2 * j + 3) * pt1;                            // P'_{j+2}
+                    pt0 = pt1;
+                    pt1 = pn;
+                    dt0 = dt1;
+                    dt1 = dn;
+                }
+                add += Pz * s0;
+                addt += Pz * s1;
+                addzz += dPz * s0;
+                const double pn = ((2 * i + 3) * zc * pz1 - (i + 1) * pz0) / (i + 2);
+                const double dn = dz0 + (2 * i + 3) * pz1;
+                pz0 = pz1;
+                pz1 = pn;
+                dz0 = dz1;
+                dz1 = dn;
+            }
+            const double r2 = y * y + x * x;
+            const double addx = -(addt * (2 / dphi) * (y / r2));
+            const double addy = addt * (2 / dphi) * (x / r2);
+            const double addz = addzz * 2 / zspan;
+            const double rr = sqrt(x * x + y * y);
+            const double G = rr + add;
+            double F;
+            if (KIND == 0) {
+                F = -(G * G - pp - twop * z - cst);
+                Fx = -(2 * G * (x / rr + addx));
+                Fy = -(2 * G * (y / rr + addy));
+                Fz = twop - 2 * G * addz;
+            } else if (KIND == 1) {
+                const double dz = d + z;
+                F = -(G * G - e2 * (dz * dz) + z * z);
+                Fx = -(2 * G * (x / rr + addx));
+                Fy = -(2 * G * (y / rr + addy));
+                Fz = twoe2 * dz - 2 * z - 2 * G * addz;
+            } else {
+                const double zz = z - zfoc;
+                F = zz * zz / aa2 + G * G / bb2 - 1.;
+                Fx = 2 * G / bb2 * (x / rr + addx);
+                Fy = 2 * G / bb2 * (y / rr + addy);
+                Fz = 2 * zz / aa2 + (2 * G / bb2) * addz;
+            }
+            const double Fp = Fx * c[L] + Fy * c[M] + Fz * c[N];
+            const double delt = -F / Fp;
+            c[X] = x + c[L] * delt;
+            c[Y] = y + c[M] * delt;
+            c[Z] = z + c[N] * delt;
+            act = fabs(delt) > tol;
+        }
+        const double Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+        c[UX] = Fx / Fp;
+        c[UY] = Fy / Fp;
+        c[UZ] = Fz / Fp;
+        wm[0] = WR;
+    }
+};
+
+// ---- Wolter-Schwarzschild : woltsurf.f95:387-476 (primary), 484-588 (secondary) ----------------
+template <bool SECONDARY>
+struct WSOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = POS | DIR;
+    static constexpr unsigned WR = POS | NRM;
+    double betas, ff, g, k;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int q = 0; q < V; q++) {
+            double *c = r[q].c;
+            const double xi = c[X], yi = c[Y], zi = c[Z];
+            double delt = 100., Fx = 0., Fy = 0., Fz = 0.;
+            int cnt = 0;
+            if (!sel[q]) {
+                wm[q] = 0;
+                continue;
+            }
+            while (fabs(delt) > PXF_TOL_1EM8) {
+                const double x = c[X], y = c[Y], z = c[Z];
+                const double r2 = x * x + y * y;
+                const double rr = sqrt(r2);
+                double F, Fb;
+                if (!SECONDARY) {
+                    double beta = asin(rr / ff);
+                    const bool flag = beta <= betas;
+                    double kterm;
+                    if (flag) {
+                        beta = betas;
+                        kterm = 0.;
+                    } else {
+                        const double t = tan(beta / 2);
+                        kterm = (1 / k) * (t * t) - 1;
+                    }
+                    const double sb2 = sin(betas / 2), sb = sin(beta), cb2 = cos(beta / 2), sh = sin(beta / 2);
+                    const double cb2_2 = cb2 * cb2;
+                    const double pk = pow(kterm, 1 - k);
+                    F = -z - ff * (sb2 * sb2) + ff * ff * (sb * sb) / (4 * ff * (sb2 * sb2)) + g * ((cb2_2 * cb2) * cb2) * pk;
+                    Fb = ff * ff * sb * cos(beta) / (2 * ff * (sb2 * sb2)) - 2 * g * (cb2_2 * cb2) * sh * pk +
+                         g * (1 - k) * cb2 * sh * pow(kterm, -k) * (1 / k);
+                    Fz = -1.;
+                    if (flag) {
+                        Fb = ff * ff * sin(betas) * cos(betas) / (2 * ff * (sb2 * sb2)) +
+                             g * (1 - k) * cos(betas / 2) * sin(betas / 2) * (1 / k);
+                        const double q2 = r2 + z * z;
+                        F = F + (rr - ff * sin(betas)) * z / q2 * Fb;
+                        Fz = Fz + (rr - ff * sin(betas)) * (r2 - z * z) / (q2 * q2) * Fb;
+                    }
+                    const double den = sqrt(1 - r2 / (ff * ff));
+                    Fx = Fb * (x / den / ff / rr);
+                    Fy = Fb * (y / den / ff / rr);
+                } else {
+                    double beta = atan2(rr, z);
+                    const bool flag = beta <= betas;
+                    double kterm, a;
+                    if (flag) {
+                        beta = betas;
+                        kterm = 0.;
+                        a = 1 / ff;
+                    } else {
+                        const double t = tan(beta / 2);
+                        kterm = (1 / k) * (t * t) - 1;
+                        a = (1 - cos(beta)) / (1 - cos(betas)) / ff + (1 + cos(beta)) / (2 * g) * pow(kterm, 1 + k);
+                    }
+                    F = -z + cos(beta) / a;
+                    if (flag) {
+                        const double cb2 = cos(betas / 2), sbs = sin(betas);
+                        const double dadbs = sbs / ff / (1 - cos(betas)) +
+                                             (k + 1) * (cos(betas) + 1) * tan(betas / 2) / (cb2 * cb2) / 2 / g / k;
+                        const double dbdzs = -(sbs * sbs) / rr;
+                        const double gam = (-ff * sbs - ff * ff * cos(betas) * dadbs) * dbdzs;
+                        F = F + gam * (z - rr / tan(betas));
+                        Fx = -2. / tan(betas) * x / rr;
+                        Fy = -2. / tan(betas) * y / rr;
+                        Fz = gam - 1.;
+                    } else {
+                        const double cb2 = cos(beta / 2);
+                        const double r3 = r2 + z * z;
+                        const double dadb = sin(beta) / ff / (1 - cos(betas)) - sin(beta) / (2 * g) * pow(kterm, 1 + k) +
+                                            (k + 1) * (cos(beta) + 1) * tan(beta / 2) * pow(kterm, k) / 2 / g / k / (cb2 * cb2);
+                        Fb = -sin(beta) / a - cos(beta) / (a * a) * dadb;
+                        Fx = Fb * (x * z / r3 / rr);
+                        Fy = Fb * (y * z / r3 / rr);
+                        Fz = -1. + Fb * (-rr / r3);
+                    }
+                }
+                const double Fp = Fx * c[L] + Fy * c[M] + Fz * c[N];
+                delt = -F / Fp;
+                c[X] = x + c[L] * delt;
+                c[Y] = y + c[M] * delt;
+                c[Z] = z + c[N] * delt;
+                if (cnt > 25 || delt != delt) {  // :454-460 / :566-572: give up, restore the start point
+                    delt = 0.;
+                    c[X] = xi;
+                    c[Y] = yi;
+                    c[Z] = zi;
+                    cnt = 1000;
+                }
+                cnt = cnt + 1;
+            }
+            if (cnt < 26) {
+                const double Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+                const double sgn = SECONDARY ? 1. : -1.;  // the primary stores the inward normal (:470-472)
+                c[UX] = sgn * Fx / Fp;
+                c[UY] = sgn * Fy / Fp;
+                c[UZ] = sgn * Fz / Fp;
+                wm[q] = WR;
+            } else {
+                wm[q] = POS;  // position restored, normal left as it was
+            }
+        }
+    }
+};
+
+static Cols cols9(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                  double *ux, double *uy, double *uz)
+{
+    Cols c{};
+    c.p[X] = x;
+    c.p[Y] = y;
+    c.p[Z] = z;
+    c.p[L] = const_cast<double *>(l);
+    c.p[M] = const_cast<double *>(m);
+    c.p[N] = const_cast<double *>(n);
+    c.p[UX] = ux;
+    c.p[UY] = uy;
+    c.p[UZ] = uz;
+    return c;
+}
+
+template <int KIND>
+static int fold_ll(LLOp<KIND> &op, double zmax, double zmin, double dphi, const double *coeff,
+                   const int32_t *axial, const int32_t *az, int32_t cnum)
+{
+    if (cnum < 0 || (cnum > 0 && (!coeff || !axial || !az))) return PXF_EINVAL;
+    int ka = 0, kt = 0;
+    for (int a = 0; a < cnum; a++) {
+        if (axial[a] < 0 || az[a] < 0) return PXF_EINVAL;
+        if (axial[a] > ka) ka = axial[a];
+        if (az[a] > kt) kt = az[a];
+    }
+    if ((ka + 1) * (kt + 1) > kLLMax) return PXF_ERANGE;
+    for (int i = 0; i < kLLMax; i++) op.cmat[i] = 0.;
+    for (int a = 0; a < cnum; a++) op.cmat[axial[a] * (kt + 1) + az[a]] += coeff[a];
+    op.ka = ka;
+    op.kt = kt;
+    op.zmid = (zmax + zmin) / 2.;
+    op.zhalf = (zmax - zmin) / 2.;
+    op.dphi = dphi;
+    op.zspan = zmax - zmin;
+    op.two_over_dphi = 0.;
+    op.two_over_dz = 0.;
+    return PXF_OK;
+}
+
+}  // namespace pxf
+
+using namespace pxf;
+
+extern "C" {
+
+int pxf_woltersine(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                   double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double amp,
+                   double freq, const uint8_t *mask, pxf_stream_t stream)
+{
+    double p, d, e;
+    pxf_wolter_params(r0, z0, 1., &p, &d, &e);  // thetah = 3 alpha, thetap = alpha  <=> psi = 1 (:177-178)
+    WolterSineOp op{2 * p, p * p, 4 * (e * e) * p * d / (e * e - 1), amp, freq, (double)acosf(-1.f),
+                    (double)(2.f * acosf(-1.f))};
+    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+}
+
+int pxf_wolterprimll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double zmax,
+                     double zmin, double dphi, const double *coeff, const int32_t *axial, const int32_t *az,
+                     int32_t cnum, const uint8_t *mask, pxf_stream_t stream)
+{
+    LLOp<0> op{};
+    int rc = fold_ll(op, zmax, zmin, dphi, coeff, axial, az, cnum);
+    if (rc != PXF_OK) return rc;
+    double p, d, e;
+    pxf_wolter_params(r0, z0, 1., &p, &d, &e);
+    op.twop = 2 * p;
+    op.pp = p * p;
+    op.cst = 4 * (e * e) * p * d / (e * e - 1);
+    op.tol = PXF_TOL_1EM10;
+    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+}
+
+int pxf_woltersecll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                    double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double psi,
+                    double zmax, double zmin, double dphi, const double *coeff, const int32_t *axial,
+                    const int32_t *az, int32_t cnum, const uint8_t *mask, pxf_stream_t stream)
+{
+    LLOp<1> op{};
+    int rc = fold_ll(op, zmax, zmin, dphi, coeff, axial, az, cnum);
+    if (rc != PXF_OK) return rc;
+    double p, d, e;
+    pxf_wolter_params(r0, z0, psi, &p, &d, &e);
+    op.e2 = e * e;
+    op.twoe2 = 2 * (e * e);
+    op.d = d;
+    op.tol = (double)1.e-7f;  // :312
+    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+}
+
+int pxf_ellipsoidwoltll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                        double *ux, double *uy, double *uz, int64_t num, double r0, double z0, double psi,
+                        double S, double zmax, double zmin, double dphi, const double *coeff,
+                        const int32_t *axial, const int32_t *az, int32_t cnum, const uint8_t *mask,
+                        pxf_stream_t stream)
+{
+    LLOp<2> op{};
+    int rc = fold_ll(op, zmax, zmin, dphi, coeff, axial, az, cnum);
+    if (rc != PXF_OK) return rc;
+    // woltsurf.f95:656-664, host libm
+    const double P = r0 / sin((psi * asin(r0 / z0) - asin(r0 / S)) / (1 + psi));
+    const double ff = (S + P) / 2.;
+    const double bq = -(r0 * r0 + (ff - P) * (ff - P) + ff * ff);
+    const double cq = ff * ff * ((ff - P) * (ff - P));
+    const double aa = sqrt((-bq + sqrt(bq * bq - 4 * cq)) / 2.);
+    const double bb = sqrt(aa * aa - ff * ff);
+    op.aa2 = aa * aa;
+    op.bb2 = bb * bb;
+    op.zfoc = ff - P + z0;
+    op.tol = PXF_TOL_1EM10;
+    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+}
+
+static void chase(double alpha, double z0, double psi, double &betas, double &ff, double &g, double &k)
+{
+    betas = 4 * alpha;  // woltsurf.f95:398-401
+    ff = z0 / cos(betas);
+    g = ff / psi;
+    const double t = tan(betas / 2);
+    k = t * t;
+}
+
+int pxf_wsprimary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                  double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                  const uint8_t *mask, pxf_stream_t stream)
+{
+    WSOp<false> op{};
+    chase(alpha, z0, psi, op.betas, op.ff, op.g, op.k);
+    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+}
+
+int pxf_wssecondary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                    double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                    const uint8_t *mask, pxf_stream_t stream)
+{
+    WSOp<true> op{};
+    chase(alpha, z0, psi, op.betas, op.ff, op.g, op.k);
+    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+}
+
+}  // extern "C"

@@ -140,6 +140,52 @@ def woltersecondary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, mask=None):
     _call("pxf_woltersecondary", (x, y, z, l, m, n, ux, uy, uz), (float(r0), float(z0), float(psi)), mask)
 
 
+def woltersine(x, y, z, l, m, n, ux, uy, uz, r0, z0, amp, freq, mask=None):
+    fused.flush()
+    _call("pxf_woltersine", (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (r0, z0, amp, freq)), mask)
+
+
+def _ll_tables(coeff, axial, az):
+    ck = np.ascontiguousarray(np.asarray(coeff if not isinstance(coeff, torch.Tensor) else coeff.cpu(),
+                                         dtype=np.float64)).reshape(-1)
+    ak = np.ascontiguousarray(np.asarray(axial), dtype=np.int32).reshape(-1)
+    zk = np.ascontiguousarray(np.asarray(az), dtype=np.int32).reshape(-1)
+    if not (len(ck) == len(ak) == len(zk)):
+        raise ValueError("coeff, axial, az must have equal length")
+    return (ck, ak, zk), (ck.ctypes.data_as(_lib._DP), ak.ctypes.data_as(_lib._IP), zk.ctypes.data_as(_lib._IP), len(ck))
+
+
+def wolterprimll(x, y, z, l, m, n, ux, uy, uz, r0, z0, zmax, zmin, dphi, coeff, axial, az, mask=None):
+    keep, t = _ll_tables(coeff, axial, az)
+    fused.flush()
+    _call("pxf_wolterprimll", (x, y, z, l, m, n, ux, uy, uz),
+          tuple(float(v) for v in (r0, z0, zmax, zmin, dphi)) + t, mask)
+
+
+def woltersecll(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, zmax, zmin, dphi, coeff, axial, az, mask=None):
+    keep, t = _ll_tables(coeff, axial, az)
+    fused.flush()
+    _call("pxf_woltersecll", (x, y, z, l, m, n, ux, uy, uz),
+          tuple(float(v) for v in (r0, z0, psi, zmax, zmin, dphi)) + t, mask)
+
+
+def ellipsoidwoltll(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, S, zmax, zmin, dphi, coeff, axial, az, mask=None):
+    keep, t = _ll_tables(coeff, axial, az)
+    fused.flush()
+    _call("pxf_ellipsoidwoltll", (x, y, z, l, m, n, ux, uy, uz),
+          tuple(float(v) for v in (r0, z0, psi, S, zmax, zmin, dphi)) + t, mask)
+
+
+def wsprimary(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, mask=None):
+    fused.flush()
+    _call("pxf_wsprimary", (x, y, z, l, m, n, ux, uy, uz), (float(alpha), float(z0), float(psi)), mask)
+
+
+def wssecondary(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, mask=None):
+    fused.flush()
+    _call("pxf_wssecondary", (x, y, z, l, m, n, ux, uy, uz), (float(alpha), float(z0), float(psi)), mask)
+
+
 def wolter_params(r0, z0, psi=1.):
     o = [C.c_double() for _ in range(3)]
     _lib.lib().pxf_wolter_params(float(r0), float(z0), float(psi), *[C.byref(v) for v in o])
@@ -227,7 +273,9 @@ surfacesf = SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=co
                             tracesphere=tracesphere, tracesphereopd=tracesphereopd, tracecyl=tracecyl,
                             tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial, paraxialy=paraxialy)
 woltsurf = SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
-                           woltersecondary=woltersecondary, spocone=spocone)
+                           woltersecondary=woltersecondary, spocone=spocone, woltersine=woltersine,
+                           wolterprimll=wolterprimll, woltersecll=woltersecll, ellipsoidwoltll=ellipsoidwoltll,
+                           wsprimary=wsprimary, wssecondary=wssecondary)
 zernsurf = SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd)
 transformationsf = SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
                                    radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract)

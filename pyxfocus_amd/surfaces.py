@@ -7,6 +7,7 @@ total focus shift, like the reference).
 import numpy as np
 
 from . import analyses
+from . import conicsolve as con
 from . import transformations as tran
 from .native import surfacesf as surf
 from .native import woltsurf as wolt
@@ -15,7 +16,9 @@ from .transformations import ind_to_mask
 
 __all__ = ["flat", "zernsurf", "conic", "wolterprimary", "wolterprimarynode", "woltersecondary", "focus",
            "focusX", "focusY", "focusI", "zmodes", "sphere", "tanSphere", "cyl", "cylconic", "paraxial",
-           "paraxialY", "spoCone", "spoPrimary", "spoSecondary"]
+           "paraxialY", "spoCone", "spoPrimary", "spoSecondary", "woltersine", "primaryLL", "secondaryLL",
+           "wsPrimary", "wsSecondary", "ellipsoidPrimary", "ellipsoidSecondary", "ellipsoidPrimaryLL",
+           "ellipsoidSecondaryLL"]
 
 
 def flat(rays, ind=None, nr=None):
@@ -166,6 +169,83 @@ def woltersecondary(rays, r0, z0, psi=1.):
     """Wolter-I secondary surface - no vignetting (surfaces.py:238-243)."""
     opd, x, y, z, l, m, n, ux, uy, uz = rays
     wolt.woltersecondary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi)
+    return
+
+
+def woltersine(rays, r0, z0, amp, freq):
+    """Wolter-I primary with a sinusoidal axial perturbation (surfaces.py:265-270)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    wolt.woltersine(x, y, z, l, m, n, ux, uy, uz, r0, z0, amp, freq)
+    return
+
+
+def secondaryLL(rays, r0, z0, psi, zmax, zmin, dphi, coeff, axial, az):
+    """Legendre-Legendre deformed secondary, placed at focus (surfaces.py:292-299)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    wolt.woltersecll(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, zmax, zmin, dphi, coeff, axial, az)
+    return
+
+
+def primaryLL(rays, r0, z0, zmax, zmin, dphi, coeff, axial, az):
+    """Legendre-Legendre deformed primary, placed at focus (surfaces.py:301-307)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    wolt.wolterprimll(x, y, z, l, m, n, ux, uy, uz, r0, z0, zmax, zmin, dphi, coeff, axial, az)
+    return
+
+
+def _ws(fn, rays, r0, z0, psi, check):
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    a, p, d, e = con.woltparam(r0, z0)
+    if check is True:
+        x0, y0, zz0 = x.clone(), y.clone(), z.clone()
+    fn(x, y, z, l, m, n, ux, uy, uz, a, z0, psi)
+    if check is True:
+        return (x0 == x) & (y0 == y) & (zz0 == z)
+    return
+
+
+def wsPrimary(rays, r0, z0, psi, check=False):
+    """Wolter-Schwarzschild primary; Chase parameters from an equivalent W-I (alpha, z0).  With
+    check=True returns the mask of rays that failed to converge (did not move) (surfaces.py:331-347)."""
+    return _ws(wolt.wsprimary, rays, r0, z0, psi, check)
+
+
+def wsSecondary(rays, r0, z0, psi, check=False):
+    """Wolter-Schwarzschild secondary (surfaces.py:367-383)."""
+    return _ws(wolt.wssecondary, rays, r0, z0, psi, check)
+
+
+def ellipsoidPrimary(rays, R0, F, S, psi):
+    """Primary of an ellipsoid-hyperboloid telescope; call at focus, like Wolter-I (surfaces.py:443-460)."""
+    P, a, b, e, f = con.ellipsoidFunction(S, psi, R0, F)
+    R = b ** 2 / a
+    tran.transform(rays, 0, 0, F + f - P - a, 0, 0, 0)
+    conic(rays, R, -e ** 2)
+    tran.itransform(rays, 0, 0, F + f - P - a, 0, 0, 0)
+    return
+
+
+def ellipsoidSecondary(rays, R0, F, S, psi):
+    """Secondary of an ellipsoid-hyperboloid telescope: a Wolter secondary with the effective psi
+    of the ellipsoid geometry (surfaces.py:462-475)."""
+    P, a, b, e, f = con.ellipsoidFunction(S, psi, R0, F)
+    psi_eff = np.arctan(R0 / P) / (np.arctan(R0 / F) - np.arctan(R0 / P))
+    woltersecondary(rays, R0, F, psi=psi_eff)
+    return
+
+
+def ellipsoidPrimaryLL(rays, R0, F, S, psi, zmax, zmin, dphi, coeff, axial, az):
+    """Ellipsoid primary with Legendre-Legendre distortions (surfaces.py:477-487)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    wolt.ellipsoidwoltll(x, y, z, l, m, n, ux, uy, uz, R0, F, psi, S, zmax, zmin, dphi, coeff, axial, az)
+    return
+
+
+def ellipsoidSecondaryLL(rays, R0, F, S, psi, zmax, zmin, dphi, coeff, axial, az):
+    """Hyperboloid secondary of the ellipsoid telescope with L-L distortions (surfaces.py:489-500)."""
+    P, a, b, e, f = con.ellipsoidFunction(S, psi, R0, F)
+    psi_eff = np.arctan(R0 / P) / (np.arctan(R0 / F) - np.arctan(R0 / P))
+    secondaryLL(rays, R0, F, psi_eff, zmax, zmin, dphi, coeff, axial, az)
     return
 
 

@@ -417,3 +417,61 @@ def test_batch1_wrappers_vs_oracle(port):
             cases.call(port, fn, cols, args)
             for k, r in zip(ALLCOLS, host(rays)):
                 assert bits_equal(r, cols[k]).all(), k
+
+
+def test_batch2_wrappers_vs_oracle(port):
+    """surfaces.woltersine / primaryLL / secondaryLL / ellipsoid* / wsPrimary / wsSecondary against the
+    oracle's native entry points (wrapper glue: argument order, psi_eff, woltparam alpha, check=)."""
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from pyxfocus_amd import conicsolve as con
+    from oracle import cases
+    got = {}
+    for name, fn, cols, args in cases.cases(num=1500, seed=3):
+        if not any(name.startswith(p) for p in ("woltersine", "wolterprimll", "woltersecll", "ellipsoidwoltll",
+                                                  "wsprimary", "wssecondary")):
+            continue
+        rays = [torch.from_numpy(cols[k].copy()).cuda() for k in ALLCOLS]
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, args)
+        if name == "woltersine":
+            surf.woltersine(rays, *args)
+        elif name == "wolterprimll":
+            surf.primaryLL(rays, *args)
+        elif name == "woltersecll":
+            surf.secondaryLL(rays, *args)
+        elif name == "ellipsoidwoltll":
+            r0, z0, psi, S, zmax, zmin, dphi, cf, ax, az = args
+            surf.ellipsoidPrimaryLL(rays, r0, z0, S, psi, zmax, zmin, dphi, cf, ax, az)
+        elif name == "wsprimary":
+            fail = surf.wsPrimary(rays, cases.R0, cases.Z0, args[2], check=True)
+            moved = (want["x"] != cols["x"]) | (want["y"] != cols["y"]) | (want["z"] != cols["z"])
+            assert np.array_equal(fail.cpu().numpy(), ~moved)
+            assert abs(con.woltparam(cases.R0, cases.Z0)[0] - args[0]) < 1e-18
+        else:
+            assert surf.wsSecondary(rays, cases.R0, cases.Z0, args[2]) is None
+        tol = 2e-8 if name.startswith("ws") else 1e-10
+        for k, r in zip(ALLCOLS, host(rays)):
+            f = ~np.isnan(want[k])
+            assert (np.isnan(r) == np.isnan(want[k])).all() and np.abs(r[f] - want[k][f]).max() < tol, (name, k)
+        got[name] = True
+    assert len(got) == 6
+    # ellipsoidPrimary = transform -> conic -> itransform ; ellipsoidSecondary = woltersecondary(psi_eff)
+    rng = np.random.default_rng(4)
+    R0, F, S, psi = 220., 8400., 1e5, 1.
+    c = cases.primary_input(rng, 4000)
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    a = [c[k] for k in ALLCOLS[1:]]
+    P, ea, eb, ee, ef = con.ellipsoidFunction(S, psi, R0, F)
+    T = port.transformationsf
+    T.transform(*a, 0., 0., -(F + ef - P - ea), 0., 0., 0.)
+    port.surfacesf.conic(*a, eb ** 2 / ea, -ee ** 2)
+    T.itransform(*a, 0., 0., -(F + ef - P - ea), 0., 0., 0.)
+    T.reflect(*a[3:])
+    psi_eff = np.arctan(R0 / P) / (np.arctan(R0 / F) - np.arctan(R0 / P))
+    port.woltsurf.woltersecondary(*a, R0, F, psi_eff)
+    surf.ellipsoidPrimary(rays, R0, F, S, psi)
+    tran.reflect(rays)
+    surf.ellipsoidSecondary(rays, R0, F, S, psi)
+    for k, r in zip(ALLCOLS, host(rays)):
+        assert bits_equal(r, c[k]).all(), k
