@@ -92,6 +92,24 @@ int pxf_paraxial(const double *x, const double *y, double *l, double *m, int64_t
                  const uint8_t *mask, pxf_stream_t stream);
 int pxf_paraxialy(const double *y, double *m, int64_t num, double F, const uint8_t *mask, pxf_stream_t stream);
 
+/* torus(x,...,uz,num,rin,rout)   surfacesf.f95:468-507   (Newton; normal as the reference builds it) */
+int pxf_torus(double *x, double *y, double *z, const double *l, const double *m, const double *n, double *ux,
+              double *uy, double *uz, int64_t num, double rin, double rout, const uint8_t *mask,
+              pxf_stream_t stream);
+/* conicplus(x,...,uz,num,R,K,p,Np) / conicplusopd(opd,x,...,uz,num,R,K,p,Np,nr)   surfacesf.f95:514-638
+ * p = HOST array of Np (<= 16) even-polynomial coefficients (p[0] quadratic, p[1] quartic, ...). */
+int pxf_conicplus(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                  double *ux, double *uy, double *uz, int64_t num, double R, double K, const double *p,
+                  int32_t Np, const uint8_t *mask, pxf_stream_t stream);
+int pxf_conicplusopd(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+                     const double *n, double *ux, double *uy, double *uz, int64_t num, double R, double K,
+                     const double *p, int32_t Np, double nr, const uint8_t *mask, pxf_stream_t stream);
+/* legSurf(x,...,uz,xwidth,ywidth,order,coeff,xo,yo,Nc,num)   surfacesf.f95:642-668
+ * 2-D Legendre phase surface; only x,y,l,m,n are touched.  coeff/xo/yo HOST arrays, Nc <= 48, orders <= 12. */
+int pxf_legsurf(const double *x, const double *y, double *l, double *m, double *n, int64_t num, double xwidth,
+                double ywidth, double order, const double *coeff, const int32_t *xo, const int32_t *yo,
+                int32_t Nc, const uint8_t *mask, pxf_stream_t stream);
+
 /* ---- woltsurf.f95 ---------------------------------------------------------------------- */
 
 /* Van Speybroeck constants p,d,e from (r0,z0,psi), woltsurf.f95:18-23, evaluated on the host
@@ -153,6 +171,14 @@ int pxf_wssecondary(double *x, double *y, double *z, const double *l, const doub
                     double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
                     const uint8_t *mask, pxf_stream_t stream);
 
+/* wsprimaryBack / wssecondaryBack (x,...,uz,num,alpha,z0,psi,thick)   woltsurf.f95:726-816 / 826-933 */
+int pxf_wsprimaryback(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                      double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                      double thick, const uint8_t *mask, pxf_stream_t stream);
+int pxf_wssecondaryback(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                        double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                        double thick, const uint8_t *mask, pxf_stream_t stream);
+
 /* ---- zernsurf.f95 (+ zernset, specialFunctions.f95:142-232) ------------------------------- */
 
 /* tracezern(x,...,uz,num,coeff,rorder,aorder,arrsize,rad)   zernsurf.f95:8-101
@@ -169,6 +195,20 @@ int pxf_tracezernopd(double *opd, double *x, double *y, double *z, const double 
                      const double *n, double *ux, double *uy, double *uz, int64_t num,
                      const double *coeff, const int32_t *rorder, const int32_t *aorder,
                      int32_t arrsize, double rad, double nr, const uint8_t *mask, pxf_stream_t stream);
+
+/* tracezernrot(x,...,uz,num,coeff1,rorder1,aorder1,arrsize1,coeff2,rorder2,aorder2,arrsize2,rad,rot)
+ * zernsurf.f95:257-359: sum of two Zernike sets, the second evaluated at theta+rot (folded into one
+ * table on the host by the angle-addition identities). */
+int pxf_tracezernrot(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, const double *coeff1,
+                     const int32_t *rorder1, const int32_t *aorder1, int32_t arrsize1, const double *coeff2,
+                     const int32_t *rorder2, const int32_t *aorder2, int32_t arrsize2, double rad, double rot,
+                     const uint8_t *mask, pxf_stream_t stream);
+/* zernphase(opd,x,...,uz,num,coeff,rorder,aorder,arrsize,rad,wave)   zernsurf.f95:206-250
+ * Zernike phase plate in the z=0 plane; only opd,x,y,l,m,n are touched. */
+int pxf_zernphase(double *opd, const double *x, const double *y, double *l, double *m, double *n, int64_t num,
+                  const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
+                  double rad, double wave, const uint8_t *mask, pxf_stream_t stream);
 
 /* ---- transformationsf.f95 -------------------------------------------------------------- */
 

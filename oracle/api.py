@@ -101,6 +101,14 @@ def load_port(omp=False):
     f_wsp = sig("orc_wsprimary", *[P] * 9, i64, d, d, d)
     f_wss = sig("orc_wssecondary", *[P] * 9, i64, d, d, d)
     f_leg = sig("orc_legendre", d, i32, P, P)
+    f_wspb = sig("orc_wsprimaryback", *[P] * 9, i64, d, d, d, d)
+    f_wssb = sig("orc_wssecondaryback", *[P] * 9, i64, d, d, d, d)
+    f_tor = sig("orc_torus", *[P] * 9, i64, d, d)
+    f_cp = sig("orc_conicplus", *[P] * 9, i64, d, d, P, i32)
+    f_cpo = sig("orc_conicplusopd", *[P] * 10, i64, d, d, P, i32, d)
+    f_lgs = sig("orc_legsurf", *[P] * 5, i64, d, d, d, P, _ip, _ip, i32)
+    f_zph = sig("orc_zernphase", *[P] * 6, i64, P, _ip, _ip, i32, d, d, restype=C.c_int)
+    f_zrot = sig("orc_tracezernrot", *[P] * 9, i64, P, _ip, _ip, i32, P, _ip, _ip, i32, d, d, restype=C.c_int)
 
     def flat(x, y, z, l, m, n, ux, uy, uz):
         p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
@@ -253,6 +261,54 @@ def load_port(omp=False):
         f_leg(x, n, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def wsprimaryback(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, thick):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_wspb(*p, num, alpha, z0, psi, thick)
+
+    def wssecondaryback(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, thick):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_wssb(*p, num, alpha, z0, psi, thick)
+
+    def torus(x, y, z, l, m, n, ux, uy, uz, rin, rout):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        f_tor(*p, num, rin, rout)
+
+    def conicplus(x, y, z, l, m, n, ux, uy, uz, R, K, pp):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        pk, ppt = _f64in(pp)
+        f_cp(*p, num, R, K, ppt, len(pk))
+
+    def conicplusopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, pp, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        pk, ppt = _f64in(pp)
+        f_cpo(*p, num, R, K, ppt, len(pk), nr)
+
+    def legsurf(x, y, z, l, m, n, ux, uy, uz, xwidth, ywidth, order, coeff, xo, yo):
+        p, num = _cols(x, y, l, m, n)
+        ck, cp = _f64in(coeff)
+        xk, xp = _i32(xo)
+        yk, yp = _i32(yo)
+        f_lgs(*p, num, xwidth, ywidth, order, cp, xp, yp, len(ck))
+
+    def zernphase(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, wave):
+        p, num = _cols(opd, x, y, l, m, n)
+        ck, cp = _f64in(coeff)
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        if f_zph(*p, num, cp, rp, ap, len(ck), rad, wave) != 0:
+            raise ValueError("zernphase: (rorder, aorder) outside the reference's radial table")
+
+    def tracezernrot(x, y, z, l, m, n, ux, uy, uz, coeff1, rorder1, aorder1, coeff2, rorder2, aorder2, rad, rot):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        c1, c1p = _f64in(coeff1)
+        r1, r1p = _i32(rorder1)
+        a1, a1p = _i32(aorder1)
+        c2, c2p = _f64in(coeff2)
+        r2, r2p = _i32(rorder2)
+        a2, a2p = _i32(aorder2)
+        if f_zrot(*p, num, c1p, r1p, a1p, len(c1), c2p, r2p, a2p, len(c2), rad, rot) != 0:
+            raise ValueError("tracezernrot: (rorder, aorder) outside the reference's radial table")
+
     def wolter_params(r0, z0, psi=1.):
         o = [C.c_double() for _ in range(3)]
         f_par(r0, z0, psi, *[C.byref(v) for v in o])
@@ -263,13 +319,15 @@ def load_port(omp=False):
         surfacesf=SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd,
                                   tracesphere=tracesphere, tracesphereopd=tracesphereopd, tracecyl=tracecyl,
                                   tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial,
-                                  paraxialy=paraxialy),
+                                  paraxialy=paraxialy, torus=torus, conicplus=conicplus, conicplusopd=conicplusopd,
+                                  legsurf=legsurf),
         woltsurf=SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
                                  woltersecondary=woltersecondary, spocone=spocone, woltersine=woltersine,
                                  wolterprimll=wolterprimll, woltersecll=woltersecll,
                                  ellipsoidwoltll=ellipsoidwoltll, wsprimary=wsprimary, wssecondary=wssecondary,
-                                 legendre=legendre),
-        zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
+                                 wsprimaryback=wsprimaryback, wssecondaryback=wssecondaryback, legendre=legendre),
+        zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset,
+                                 zernphase=zernphase, tracezernrot=tracezernrot),
         transformationsf=SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
                                          radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract),
         wolter_params=wolter_params)
@@ -389,6 +447,47 @@ def load_ref(omp=False):
     def legendre(x, n):
         return (f_leg(dref(x), C.byref(C.c_int32(n))), f_legp(dref(x), C.byref(C.c_int32(n))))
 
+    f_cp = fn("surfacesf", "conicplus")
+    f_cpo = fn("surfacesf", "conicplusopd")
+    f_lgs = fn("surfacesf", "legsurf")
+    f_zph = fn("zernsurf", "zernphase")
+    f_zrot = fn("zernsurf", "tracezernrot")
+
+    def conicplus(x, y, z, l, m, n, ux, uy, uz, R, K, pp):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        pk, ppt = _f64in(pp)
+        f_cp(*p, num32(num), dref(R), dref(K), ppt, C.byref(C.c_int32(len(pk))))
+
+    def conicplusopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, pp, nr):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        pk, ppt = _f64in(pp)
+        f_cpo(*p, num32(num), dref(R), dref(K), ppt, C.byref(C.c_int32(len(pk))), dref(nr))
+
+    def legsurf(x, y, z, l, m, n, ux, uy, uz, xwidth, ywidth, order, coeff, xo, yo):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        ck, cp = _f64in(coeff)
+        xk, xp = _i32(xo)
+        yk, yp = _i32(yo)    # legSurf(x,...,uz,xwidth,ywidth,order,coeff,xo,yo,Nc,num): num is LAST
+        f_lgs(*p, dref(xwidth), dref(ywidth), dref(order), cp, xp, yp, C.byref(C.c_int32(len(ck))), num32(num))
+
+    def zernphase(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, wave):
+        p, num = _cols(opd, x, y, z, l, m, n, ux, uy, uz)
+        ck, cp = _f64in(coeff)
+        rk, rp = _i32(rorder)
+        ak, ap = _i32(aorder)
+        f_zph(*p, num32(num), cp, rp, ap, C.byref(C.c_int32(len(ck))), dref(rad), dref(wave))
+
+    def tracezernrot(x, y, z, l, m, n, ux, uy, uz, coeff1, rorder1, aorder1, coeff2, rorder2, aorder2, rad, rot):
+        p, num = _cols(x, y, z, l, m, n, ux, uy, uz)
+        c1, c1p = _f64in(coeff1)
+        r1, r1p = _i32(rorder1)
+        a1, a1p = _i32(aorder1)
+        c2, c2p = _f64in(coeff2)
+        r2, r2p = _i32(rorder2)
+        a2, a2p = _i32(aorder2)
+        f_zrot(*p, num32(num), c1p, r1p, a1p, C.byref(C.c_int32(len(c1))), c2p, r2p, a2p,
+               C.byref(C.c_int32(len(c2))), dref(rad), dref(rot))
+
     f_gr = fn("transformationsf", "grat")
 
     def grat(x, y, l, m, n, d_, order, wave):
@@ -414,7 +513,9 @@ def load_ref(omp=False):
                                   tracecylopd=mk10("surfacesf", "tracecylopd", 2),
                                   cylconic=mk9("surfacesf", "cylconic", 2),
                                   paraxial=mk9("surfacesf", "paraxial", 1),
-                                  paraxialy=mk9("surfacesf", "paraxialy", 1)),
+                                  paraxialy=mk9("surfacesf", "paraxialy", 1),
+                                  torus=mk9("surfacesf", "torus", 2), conicplus=conicplus,
+                                  conicplusopd=conicplusopd, legsurf=legsurf),
         woltsurf=SimpleNamespace(wolterprimary=mk9("woltsurf", "wolterprimary", 3),
                                  wolterprimaryopd=mk10("woltsurf", "wolterprimaryopd", 4),
                                  woltersecondary=mk9("woltsurf", "woltersecondary", 3),
@@ -423,8 +524,11 @@ def load_ref(omp=False):
                                  wolterprimll=mkll("wolterprimll", 5), woltersecll=mkll("woltersecll", 6),
                                  ellipsoidwoltll=mkll("ellipsoidwoltll", 7),
                                  wsprimary=mk9("woltsurf", "wsprimary", 3),
-                                 wssecondary=mk9("woltsurf", "wssecondary", 3), legendre=legendre),
-        zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset),
+                                 wssecondary=mk9("woltsurf", "wssecondary", 3),
+                                 wsprimaryback=mk9("woltsurf", "wsprimaryback", 4),
+                                 wssecondaryback=mk9("woltsurf", "wssecondaryback", 4), legendre=legendre),
+        zernsurf=SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernset=zernset,
+                                 zernphase=zernphase, tracezernrot=tracezernrot),
         transformationsf=SimpleNamespace(transform=mk9("transformationsf", "transform", 6),
                                          itransform=mk9("transformationsf", "itransform", 6),
                                          reflect=reflect, radgrat=radgrat, radgratw=radgratw, grat=grat,

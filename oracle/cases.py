@@ -48,6 +48,14 @@ SIG = {
     "woltsurf.ellipsoidwoltll": "x y z l m n ux uy uz",
     "woltsurf.wsprimary": "x y z l m n ux uy uz",
     "woltsurf.wssecondary": "x y z l m n ux uy uz",
+    "woltsurf.wsprimaryback": "x y z l m n ux uy uz",
+    "woltsurf.wssecondaryback": "x y z l m n ux uy uz",
+    "surfacesf.torus": "x y z l m n ux uy uz",
+    "surfacesf.conicplus": "x y z l m n ux uy uz",
+    "surfacesf.conicplusopd": "opd x y z l m n ux uy uz",
+    "surfacesf.legsurf": "x y z l m n ux uy uz",
+    "zernsurf.zernphase": "opd x y z l m n ux uy uz",
+    "zernsurf.tracezernrot": "x y z l m n ux uy uz",
 }
 ALLCOLS = "opd x y z l m n ux uy uz".split()
 
@@ -324,6 +332,59 @@ def cases(num=2048, seed=1234):
     port.woltsurf.wsprimary(*a, alpha, Z0, PSI)
     port.transformationsf.reflect(*a[3:])
     out.append(("wssecondary", "woltsurf.wssecondary", c2, (alpha, Z0, PSI)))
+
+    # ================= widening batch 3 (appended) ================================================
+    # ---- W-S back surfaces (substrate thickness 0.4 mm) -------------------------------------------
+    c = primary_input(rng, num, offaxis=5e-5)
+    c["x"] += .4 * c["x"] / np.hypot(c["x"], c["y"]); c["y"] += .4 * c["y"] / np.hypot(c["x"], c["y"])
+    out.append(("wsprimaryback", "woltsurf.wsprimaryback", c, (alpha, Z0, PSI, .4)))
+    c2 = {kk: v.copy() for kk, v in c.items()}
+    a = [c2[kk] for kk in "x y z l m n ux uy uz".split()]
+    port.woltsurf.wsprimaryback(*a, alpha, Z0, PSI, .4)
+    port.transformationsf.reflect(*a[3:])
+    out.append(("wssecondaryback", "woltsurf.wssecondaryback", c2, (alpha, Z0, PSI, .4)))
+
+    # ---- torus (tangent-plane frame), conicplus (conic + even polynomial), Newton -------------------
+    c = _randrays(rng, num)
+    c["x"] = rng.uniform(-10, 10, num); c["y"] = rng.uniform(-10, 10, num); c["z"] = rng.uniform(5, 15, num)
+    c["l"] *= .1; c["m"] *= .1
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    out.append(("torus", "surfacesf.torus", c, (200., 1500.)))
+    pp = np.array([1e-6, -2e-10, 3e-14])
+    c = _randrays(rng, num)
+    c["x"] = rng.uniform(-30, 30, num); c["y"] = rng.uniform(-30, 30, num); c["z"] = rng.uniform(20, 40, num)
+    c["l"] *= .1; c["m"] *= .1
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    out.append(("conicplus", "surfacesf.conicplus", c, (800., -.7, pp)))
+    c2 = {kk: v.copy() for kk, v in c.items()}
+    out.append(("conicplusopd", "surfacesf.conicplusopd", c2, (-600., .3, pp[:2], 1.5)))
+
+    # ---- 2-D Legendre phase surface --------------------------------------------------------------
+    c = _randrays(rng, num)
+    c["x"] = rng.uniform(-12, 12, num); c["y"] = rng.uniform(-8, 8, num)       # some |x/xwidth| > 1
+    c["l"] *= .05; c["m"] *= .05
+    c["n"] = np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2) * rng.choice([-1., 1.], num)
+    out.append(("legsurf", "surfacesf.legsurf", c, (10., 10., 1e-3, np.array([.5, -.2, .1, .05, .02]),
+                                                     np.array([1, 2, 0, 3, 5], dtype=np.int32),
+                                                     np.array([0, 1, 2, 3, 4], dtype=np.int32))))
+
+    # ---- Zernike phase surface and the two-set rotated Zernike surface --------------------------------
+    ro, ao = noll_orders(21)
+    cf = rng.normal(0., 1e-3, 21)
+    nz = 512 if num > 512 else num
+    rho = np.sqrt(rng.random(nz)) * 50.
+    th = rng.random(nz) * 2 * np.pi
+    zero = np.zeros(nz)
+    c = dict(opd=zero.copy(), x=rho * np.cos(th), y=rho * np.sin(th), z=zero.copy(),
+             l=rng.normal(0, 1e-3, nz), m=rng.normal(0, 1e-3, nz), n=None, ux=zero.copy(), uy=zero.copy(),
+             uz=np.ones(nz))
+    c["n"] = np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2) * rng.choice([-1., 1.], nz)
+    out.append(("zernphase", "zernsurf.zernphase", c, (cf, ro, ao, 50., 5e-4)))
+    c = dict(opd=zero.copy(), x=rho * np.cos(th), y=rho * np.sin(th), z=np.full(nz, 10.),
+             l=np.full(nz, 0.01), m=zero.copy(), n=np.full(nz, -math.sqrt(1 - 1e-4)),
+             ux=zero.copy(), uy=zero.copy(), uz=zero.copy())
+    ro2, ao2 = noll_orders(10)
+    out.append(("tracezernrot", "zernsurf.tracezernrot", c, (cf, ro, ao, rng.normal(0., 2e-3, 10), ro2, ao2, 50., .37)))
     return out
 
 

@@ -936,8 +936,9 @@ void orc_ellipsoidwoltll(double *x, double *y, double *z, const double *l, const
 
 /* woltsurf.f95:387-476.  26-iteration cap; a non-converged / NaN ray gets its start position
  * back and keeps its old normal. */
-void orc_wsprimary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
-                   double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi)
+static void wsprimary_core(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                           double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                           int back, double thick)
 {
     const double betas = 4 * alpha, ff = z0 / cos(betas), g = ff / psi;
     const double tb = tan(betas / 2), k = tb * tb;
@@ -946,7 +947,15 @@ void orc_wsprimary(double *x, double *y, double *z, const double *l, const doubl
         int c = 0, flag;
         const double xi = x[i], yi = y[i], zi = z[i];
         while (fabs(delt) > TOL_1EM8) {
-            beta = asin(sqrt(x[i] * x[i] + y[i] * y[i]) / ff);
+            /* wsprimaryBack (woltsurf.f95:726-816): the surface is evaluated at the radius shrunk by `thick` */
+            double xe = x[i], ye = y[i];
+            if (back) {
+                double rb = sqrt(x[i] * x[i] + y[i] * y[i]);
+                double th = atan2(y[i], x[i]);
+                xe = (rb - thick) * cos(th);
+                ye = (rb - thick) * sin(th);
+            }
+            beta = asin(sqrt(xe * xe + ye * ye) / ff);
             flag = 0;
             if (beta <= betas) {
                 beta = betas;
@@ -967,7 +976,7 @@ void orc_wsprimary(double *x, double *y, double *z, const double *l, const doubl
             Fz = -1.;
             if (flag == 1) {
                 double sb2 = sin(betas / 2);
-                r = sqrt(x[i] * x[i] + y[i] * y[i]);
+                r = sqrt(xe * xe + ye * ye);
                 Fb = ff * ff * sin(betas) * cos(betas) / (2 * ff * (sb2 * sb2)) +
                      g * (1 - k) * cos(betas / 2) * sin(betas / 2) * (1 / k);
                 F = F + (r - ff * sin(betas)) * z[i] / (r * r + z[i] * z[i]) * Fb;
@@ -975,9 +984,9 @@ void orc_wsprimary(double *x, double *y, double *z, const double *l, const doubl
                               ((r * r + z[i] * z[i]) * (r * r + z[i] * z[i])) * Fb;
             }
             {
-                double r2 = x[i] * x[i] + y[i] * y[i];
-                dbdx = x[i] / sqrt(1 - r2 / (ff * ff)) / ff / sqrt(r2);
-                dbdy = y[i] / sqrt(1 - r2 / (ff * ff)) / ff / sqrt(r2);
+                double r2 = xe * xe + ye * ye;
+                dbdx = xe / sqrt(1 - r2 / (ff * ff)) / ff / sqrt(r2);
+                dbdy = ye / sqrt(1 - r2 / (ff * ff)) / ff / sqrt(r2);
             }
             Fx = Fb * dbdx;
             Fy = Fb * dbdy;
@@ -1004,9 +1013,23 @@ void orc_wsprimary(double *x, double *y, double *z, const double *l, const doubl
     }
 }
 
-/* woltsurf.f95:484-588 */
-void orc_wssecondary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
-                     double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi)
+void orc_wsprimary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                   double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi)
+{
+    wsprimary_core(x, y, z, l, m, n, ux, uy, uz, num, alpha, z0, psi, 0, 0.);
+}
+
+void orc_wsprimaryback(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                       double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                       double thick)
+{
+    wsprimary_core(x, y, z, l, m, n, ux, uy, uz, num, alpha, z0, psi, 1, thick);
+}
+
+/* woltsurf.f95:484-588 (and wssecondaryBack, :826-933, with back=1) */
+static void wssecondary_core(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                             double *ux, double *uy, double *uz, int64_t num, double alpha, double z0,
+                             double psi, int back, double thick)
 {
     const double betas = 4 * alpha, ff = z0 / cos(betas), g = ff / psi;
     const double tb = tan(betas / 2), k = tb * tb;
@@ -1015,7 +1038,14 @@ void orc_wssecondary(double *x, double *y, double *z, const double *l, const dou
         int c = 0, flag;
         const double xi = x[i], yi = y[i], zi = z[i];
         while (fabs(delt) > TOL_1EM8) {
-            double rr = sqrt(x[i] * x[i] + y[i] * y[i]);
+            double xe = x[i], ye = y[i];
+            if (back) {
+                double rb = sqrt(x[i] * x[i] + y[i] * y[i]);
+                double th = atan2(y[i], x[i]);
+                xe = (rb - thick) * cos(th);
+                ye = (rb - thick) * sin(th);
+            }
+            double rr = sqrt(xe * xe + ye * ye);
             beta = atan2(rr, z[i]);
             flag = 0;
             if (beta <= betas) {
@@ -1038,17 +1068,17 @@ void orc_wssecondary(double *x, double *y, double *z, const double *l, const dou
                 double gam = (-ff * sin(betas) - ff * ff * cos(betas) * dadbs) * dbdzs;
                 Fb = 0.;
                 F = F + gam * (z[i] - rr / tan(betas));
-                Fx = -2. / tan(betas) * x[i] / rr;
-                Fy = -2. / tan(betas) * y[i] / rr;
+                Fx = -2. / tan(betas) * xe / rr;
+                Fy = -2. / tan(betas) * ye / rr;
                 Fz = gam - 1.;
             } else {
                 double cb2 = cos(beta / 2);
-                double r3 = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
+                double r3 = xe * xe + ye * ye + z[i] * z[i];
                 dadb = sin(beta) / ff / (1 - cos(betas)) - sin(beta) / (2 * g) * pow(kterm, 1 + k) +
                        (k + 1) * (cos(beta) + 1) * tan(beta / 2) * pow(kterm, k) / 2 / g / k / (cb2 * cb2);
                 Fb = -sin(beta) / a - cos(beta) / (a * a) * dadb;
-                dbdx = x[i] * z[i] / r3 / rr;
-                dbdy = y[i] * z[i] / r3 / rr;
+                dbdx = xe * z[i] / r3 / rr;
+                dbdy = ye * z[i] / r3 / rr;
                 dbdz = -rr / r3;
                 Fx = Fb * dbdx;
                 Fy = Fb * dbdy;
@@ -1075,4 +1105,213 @@ void orc_wssecondary(double *x, double *y, double *z, const double *l, const dou
             uz[i] = Fz / Fp;
         }
     }
+}
+
+void orc_wssecondary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi)
+{
+    wssecondary_core(x, y, z, l, m, n, ux, uy, uz, num, alpha, z0, psi, 0, 0.);
+}
+
+void orc_wssecondaryback(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                         double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
+                         double thick)
+{
+    wssecondary_core(x, y, z, l, m, n, ux, uy, uz, num, alpha, z0, psi, 1, thick);
+}
+
+/* ==================================================================================== */
+/* Widening batch 3: torus, conicplus[opd], legSurf, zernphase, tracezernrot.               */
+
+/* surfacesf.f95:468-507.  Note the normal: Fp = sqrt(Fx^2+Fy^2) WITHOUT Fz (:501) -- reproduced. */
+void orc_torus(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+               double *ux, double *uy, double *uz, int64_t num, double rin, double rout)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double delt = 100., Fx = 0., Fy = 0., Fz = 0., Fp;
+        int it = 0;
+        while (fabs(delt) > TOL_1EM10 && it < ORC_NEWTON_CAP) {
+            double zr = z[i] + rin + rout;
+            double t = zr * zr + y[i] * y[i] + x[i] * x[i] + rout * rout - rin * rin;
+            double F = t * t - (4 * (rout * rout) * (y[i] * y[i] + zr * zr));
+            double zr2 = rin + rout + z[i];
+            Fx = 4 * x[i] * (-(rin * rin) + zr2 * zr2 + rout * rout + x[i] * x[i] + y[i] * y[i]);
+            double q = 2 * rin * (rout + z[i]) + 2 * rout * z[i] + z[i] * z[i] + y[i] * y[i] + x[i] * x[i];
+            Fy = 4 * y[i] * q;
+            Fz = 4 * (rout + rin + z[i]) * q;
+            Fp = Fx * l[i] + Fy * m[i] + Fz * n[i];
+            delt = -F / Fp;
+            x[i] = x[i] + l[i] * delt;
+            y[i] = y[i] + m[i] * delt;
+            z[i] = z[i] + n[i] * delt;
+            it++;
+        }
+        Fp = sqrt(Fx * Fx + Fy * Fy);
+        ux[i] = Fx / Fp;
+        uy[i] = Fy / Fp;
+        uz[i] = Fz / Fp;
+    }
+}
+
+/* surfacesf.f95:514-572 (opd==NULL) and :579-638 */
+static void conicplus_core(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+                           const double *n, double *ux, double *uy, double *uz, int64_t num, double R,
+                           double K, const double *p, int Np, double nr)
+{
+    const double Fz = 1., c = 1 / R;
+    for (int64_t i = 0; i < num; i++) {
+        double delt = 100., Fx = 0., Fy = 0., Fp;
+        int it = 0;
+        while (fabs(delt) > TOL_1EM10 && it < ORC_NEWTON_CAP) {
+            double rad = sqrt(x[i] * x[i] + y[i] * y[i]);
+            double a0 = 0., a1 = 0.;
+            for (int j = 1; j <= Np; j++) {
+                a0 = a0 + p[j - 1] * powi(rad, 2 * j);
+                a1 = a1 + p[j - 1] * (2 * j) * powi(rad, 2 * j - 1);
+            }
+            double sq = sqrt(1 - (K + 1) * (c * c) * (rad * rad));
+            double denom = sq + 1;
+            double F = z[i] - c * (rad * rad) / denom + a0;
+            double Fr = -(2 * c * rad / denom + ((K + 1) * ((rad * rad) * rad) * ((c * c) * c)) / ((denom * denom) * sq)) + a1;
+            Fx = Fr * x[i] / rad;
+            Fy = Fr * y[i] / rad;
+            Fp = Fx * l[i] + Fy * m[i] + Fz * n[i];
+            delt = -F / Fp;
+            x[i] = x[i] + l[i] * delt;
+            y[i] = y[i] + m[i] * delt;
+            z[i] = z[i] + n[i] * delt;
+            if (opd) opd[i] = opd[i] + delt * nr;
+            it++;
+        }
+        Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+        ux[i] = Fx / Fp;
+        uy[i] = Fy / Fp;
+        uz[i] = Fz / Fp;
+    }
+}
+
+void orc_conicplus(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                   double *ux, double *uy, double *uz, int64_t num, double R, double K, const double *p,
+                   int32_t Np)
+{
+    conicplus_core(NULL, x, y, z, l, m, n, ux, uy, uz, num, R, K, p, Np, 0.);
+}
+
+void orc_conicplusopd(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+                      const double *n, double *ux, double *uy, double *uz, int64_t num, double R, double K,
+                      const double *p, int32_t Np, double nr)
+{
+    conicplus_core(opd, x, y, z, l, m, n, ux, uy, uz, num, R, K, p, Np, nr);
+}
+
+/* surfacesf.f95:642-668 */
+void orc_legsurf(const double *x, const double *y, double *l, double *m, double *n, int64_t num,
+                 double xwidth, double ywidth, double order, const double *coeff, const int32_t *xo,
+                 const int32_t *yo, int32_t Nc)
+{
+    for (int64_t i = 0; i < num; i++) {
+        double dphidx = 0, dphidy = 0;
+        for (int j = 0; j < Nc; j++) {
+            dphidx = dphidx + coeff[j] * legendre(y[i] / ywidth, yo[j]) * legendrep(x[i] / xwidth, xo[j]);
+            dphidy = dphidy + coeff[j] * legendrep(y[i] / ywidth, yo[j]) * legendre(x[i] / xwidth, xo[j]);
+        }
+        l[i] = l[i] + dphidx * order / xwidth;
+        m[i] = m[i] + dphidy * order / ywidth;
+        n[i] = n[i] / fabs(n[i]) * sqrt(1. - l[i] * l[i] - m[i] * m[i]);
+    }
+}
+
+/* zernsurf.f95:206-250 */
+int orc_zernphase(double *opd, const double *x, const double *y, double *l, double *m, double *n,
+                  int64_t num, const double *coeff, const int32_t *rorder, const int32_t *aorder,
+                  int32_t arrsize, double rad, double wave)
+{
+    const int radnum = zern_radnum(arrsize);
+    for (int c = 0; c < arrsize; c++) {
+        int am = aorder[c] < 0 ? -aorder[c] : aorder[c];
+        if (rorder[c] < 0 || rorder[c] >= radnum || am > rorder[c] || ((rorder[c] - am) & 1)) return -1;
+    }
+    double *zern = (double *)malloc(sizeof(double) * 3 * (size_t)arrsize);
+    double *rhoder = zern + arrsize, *thetader = zern + 2 * arrsize;
+    double *rnm = (double *)calloc(2 * (size_t)radnum * radnum, sizeof(double));
+    double *rpr = rnm + (size_t)radnum * radnum;
+    for (int64_t i = 0; i < num; i++) {
+        double rho = sqrt(x[i] * x[i] + y[i] * y[i]);
+        double theta = atan2(y[i], x[i]);
+        zernset(rho / rad, theta, rorder, aorder, arrsize, zern, rhoder, thetader, rnm, rpr, radnum);
+        double F = 0., Frho = 0., Ftheta = 0.;
+        for (int c = 0; c < arrsize; c++) {
+            F = F + coeff[c] * zern[c];
+            Frho = Frho + coeff[c] * rhoder[c] / rad;
+            Ftheta = Ftheta + coeff[c] * thetader[c];
+        }
+        double Fx = (x[i] / rho) * Frho + (-y[i] / rho) * Ftheta / rho;
+        double Fy = (y[i] / rho) * Frho + (x[i] / rho) * Ftheta / rho;
+        l[i] = l[i] + Fx * wave;
+        m[i] = m[i] + Fy * wave;
+        n[i] = copysign(sqrt(1. - l[i] * l[i] - m[i] * m[i]), n[i]);
+        opd[i] = opd[i] + F * wave;
+    }
+    free(zern);
+    free(rnm);
+    return 0;
+}
+
+/* zernsurf.f95:257-359 (serial; the reference's OpenMP build has a data race here) */
+int orc_tracezernrot(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, const double *coeff1,
+                     const int32_t *rorder1, const int32_t *aorder1, int32_t n1, const double *coeff2,
+                     const int32_t *rorder2, const int32_t *aorder2, int32_t n2, double rad, double rot)
+{
+    const int rn1 = zern_radnum(n1), rn2 = zern_radnum(n2);
+    for (int c = 0; c < n1; c++) {
+        int am = aorder1[c] < 0 ? -aorder1[c] : aorder1[c];
+        if (rorder1[c] < 0 || rorder1[c] >= rn1 || am > rorder1[c] || ((rorder1[c] - am) & 1)) return -1;
+    }
+    for (int c = 0; c < n2; c++) {
+        int am = aorder2[c] < 0 ? -aorder2[c] : aorder2[c];
+        if (rorder2[c] < 0 || rorder2[c] >= rn2 || am > rorder2[c] || ((rorder2[c] - am) & 1)) return -1;
+    }
+    int nmx = n1 > n2 ? n1 : n2, rmx = rn1 > rn2 ? rn1 : rn2;
+    double *zern = (double *)malloc(sizeof(double) * 3 * (size_t)nmx);
+    double *rhoder = zern + nmx, *thetader = zern + 2 * nmx;
+    double *rnm = (double *)calloc(2 * (size_t)rmx * rmx, sizeof(double));
+    double *rpr = rnm + (size_t)rmx * rmx;
+    for (int64_t i = 0; i < num; i++) {
+        double delta = 100., Fx = 0., Fy = 0., Fz = 0., Fp;
+        int it = 0;
+        while (fabs(delta) > TOL_1EM10 && it < ORC_NEWTON_CAP) {
+            double rho = sqrt(x[i] * x[i] + y[i] * y[i]);
+            double theta = atan2(y[i], x[i]);
+            double F = z[i], Frho = 0., Ftheta = 0.;
+            zernset(rho / rad, theta, rorder1, aorder1, n1, zern, rhoder, thetader, rnm, rpr, rn1);
+            for (int c = 0; c < n1; c++) {
+                F = F - coeff1[c] * zern[c];
+                Frho = Frho - coeff1[c] * rhoder[c] / rad;
+                Ftheta = Ftheta - coeff1[c] * thetader[c];
+            }
+            zernset(rho / rad, theta + rot, rorder2, aorder2, n2, zern, rhoder, thetader, rnm, rpr, rn2);
+            for (int c = 0; c < n2; c++) {
+                F = F - coeff2[c] * zern[c];
+                Frho = Frho - coeff2[c] * rhoder[c] / rad;
+                Ftheta = Ftheta - coeff2[c] * thetader[c];
+            }
+            Fx = (x[i] / rho) * Frho + (-y[i] / rho) * Ftheta / rho;
+            Fy = (y[i] / rho) * Frho + (x[i] / rho) * Ftheta / rho;
+            Fz = 1.;
+            Fp = Fx * l[i] + Fy * m[i] + Fz * n[i];
+            delta = -F / Fp;
+            x[i] = x[i] + l[i] * delta;
+            y[i] = y[i] + m[i] * delta;
+            z[i] = z[i] + n[i] * delta;
+            it++;
+        }
+        Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+        ux[i] = Fx / Fp;
+        uy[i] = Fy / Fp;
+        uz[i] = Fz / Fp;
+    }
+    free(zern);
+    free(rnm);
+    return 0;
 }

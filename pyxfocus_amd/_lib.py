@@ -43,6 +43,14 @@ _SIGS = {
     "pxf_ellipsoidwoltll": [_P] * 9 + [_i64] + [_d] * 7 + [_DP, _IP, _IP, _i32, _P, _P],
     "pxf_wsprimary": [_P] * 9 + [_i64, _d, _d, _d, _P, _P],
     "pxf_wssecondary": [_P] * 9 + [_i64, _d, _d, _d, _P, _P],
+    "pxf_wsprimaryback": [_P] * 9 + [_i64, _d, _d, _d, _d, _P, _P],
+    "pxf_wssecondaryback": [_P] * 9 + [_i64, _d, _d, _d, _d, _P, _P],
+    "pxf_torus": [_P] * 9 + [_i64, _d, _d, _P, _P],
+    "pxf_conicplus": [_P] * 9 + [_i64, _d, _d, _DP, _i32, _P, _P],
+    "pxf_conicplusopd": [_P] * 10 + [_i64, _d, _d, _DP, _i32, _d, _P, _P],
+    "pxf_legsurf": [_P] * 5 + [_i64, _d, _d, _d, _DP, _IP, _IP, _i32, _P, _P],
+    "pxf_tracezernrot": [_P] * 9 + [_i64, _DP, _IP, _IP, _i32, _DP, _IP, _IP, _i32, _d, _d, _P, _P],
+    "pxf_zernphase": [_P] * 6 + [_i64, _DP, _IP, _IP, _i32, _d, _d, _P, _P],
     "pxf_spocone": [_P] * 9 + [_i64, _d, _d, _P, _P],
     "pxf_grat": [_P] * 3 + [_i64, _d, _d, _P, _P, _P],
     "pxf_refract": [_P] * 6 + [_i64, _d, _d, _P, _P],

@@ -40,6 +40,70 @@ constexpr double zh1(double n, double m)
     return .5 * (m + 4) * (m + 3) - (m + 4) * zh2(n, m) + zh3(n, m) * (n + m + 6) * (n - m - 4) / 8.;
 }
 
+// Value and gradient of  S(x,y) = sum_i coeff_i Z_i(rho/rad, theta)  from the folded (Ac,As) table:
+// returns S, and the cartesian gradient (dS/dx, dS/dy).  rho == 0 gives NaN, as the reference's
+// division by rho does (zernsurf.f95:63-66).
+template <int NMAX>
+__device__ __forceinline__ void zern_eval(const double2 *__restrict__ tab, double x, double y, double rad,
+                                          double inv_rad, double &S, double &Sx, double &Sy)
+{
+    // one reciprocal per evaluation instead of nine divides (an IEEE fp64 divide is ~11 VALU
+    // instructions; this kernel is VALU-bound and tolerance-parity, so 1/rho is shared)
+    const double rho = sqrt(x * x + y * y);
+    const double inv_rho = 1. / rho;
+    const double ct = x * inv_rho, st = y * inv_rho;  // cos/sin(atan2(y,x))
+    const double rp = rho * inv_rad;
+    const double inv_rp = rad * inv_rho;
+    const double irp2 = inv_rp * inv_rp, irp3 = irp2 * inv_rp;
+    double cm[NMAX + 1], sm[NMAX + 1], pw[NMAX + 1];
+    cm[0] = 1.;
+    sm[0] = 0.;
+    pw[0] = 1.;
+#pragma unroll
+    for (int k = 1; k <= NMAX; k++) {
+        cm[k] = cm[k - 1] * ct - sm[k - 1] * st;
+        sm[k] = sm[k - 1] * ct + cm[k - 1] * st;
+        pw[k] = pw[k - 1] * rp;
+    }
+    double Sv = 0., Sr = 0., St = 0.;
+#pragma unroll
+    for (int nn = 0; nn <= NMAX; nn++) {
+        double R2 = 0., Rp2 = 0., R4 = 0., Rp4 = 0.;  // R_n^{m+2}, R_n^{m+4} of the chain
+#pragma unroll
+        for (int mm = nn; mm >= 0; mm -= 2) {
+            double R, Rp;
+            if (mm == nn) {
+                R = pw[nn];
+                Rp = nn == 0 ? 0. : (double)nn * pw[nn > 0 ? nn - 1 : 0];
+            } else if (mm == nn - 2) {
+                R = (double)nn * pw[nn] - (double)(nn - 1) * pw[nn - 2];
+                const double dnn = (double)nn * pw[nn - 1];
+                const double dn2 = nn - 2 == 0 ? 0. : (double)(nn - 2) * pw[nn > 2 ? nn - 3 : 0];
+                Rp = (double)nn * dnn - (double)(nn - 1) * dn2;
+            } else {
+                const double h3 = zh3(nn, mm), h2 = zh2(nn, mm), h1 = zh1(nn, mm);
+                const double g = h2 + h3 * irp2;
+                R = h1 * R4 + g * R2;
+                Rp = h1 * Rp4 + g * Rp2 - 2 * h3 * irp3 * R2;
+            }
+            R4 = R2;
+            Rp4 = Rp2;
+            R2 = R;
+            Rp2 = Rp;
+            const double2 a = tab[zern_pair(nn, mm)];
+            const double t1 = a.x * cm[mm] + a.y * sm[mm];
+            Sv += R * t1;
+            Sr += Rp * t1;
+            if (mm > 0) St += R * ((double)mm * (a.y * cm[mm] - a.x * sm[mm]));
+        }
+    }
+    const double Srho = Sr * inv_rad;   // dS/drho
+    const double Sth = St * inv_rho;    // (1/rho) dS/dtheta
+    S = Sv;
+    Sx = ct * Srho - st * Sth;
+    Sy = st * Srho + ct * Sth;
+}
+
 template <int NMAX>
 struct ZernOp {
     static constexpr int MAXV = 1;
@@ -72,59 +136,14 @@ struct ZernOp {
         const double l = c[L], m = c[M], n = c[N];
         double x = c[X], y = c[Y], z = c[Z];
         double t = 0., Fx = 0., Fy = 0., Fz = 0.;
+        const double inv_rad = 1. / rad;
         bool act = sel[0];
         for (int it = 0; act && it < kNewtonCap; it++) {
-            const double rho = sqrt(x * x + y * y);
-            const double ct = x / rho, st = y / rho;  // cos/sin(atan2(y,x)); rho==0 -> NaN as the reference
-            const double rp = rho / rad;
-            const double irp2 = 1. / (rp * rp), irp3 = irp2 / rp;
-            double cm[NMAX + 1], sm[NMAX + 1], pw[NMAX + 1];
-            cm[0] = 1.;
-            sm[0] = 0.;
-            pw[0] = 1.;
-#pragma unroll
-            for (int k = 1; k <= NMAX; k++) {
-                cm[k] = cm[k - 1] * ct - sm[k - 1] * st;
-                sm[k] = sm[k - 1] * ct + cm[k - 1] * st;
-                pw[k] = pw[k - 1] * rp;
-            }
-            double S = 0., Sr = 0., St = 0.;
-#pragma unroll
-            for (int nn = 0; nn <= NMAX; nn++) {
-                double R2 = 0., Rp2 = 0., R4 = 0., Rp4 = 0.;  // R_n^{m+2}, R_n^{m+4} of the chain
-#pragma unroll
-                for (int mm = nn; mm >= 0; mm -= 2) {
-                    double R, Rp;
-                    if (mm == nn) {
-                        R = pw[nn];
-                        Rp = nn == 0 ? 0. : (double)nn * pw[nn > 0 ? nn - 1 : 0];
-                    } else if (mm == nn - 2) {
-                        R = (double)nn * pw[nn] - (double)(nn - 1) * pw[nn - 2];
-                        const double dnn = (double)nn * pw[nn - 1];
-                        const double dn2 = nn - 2 == 0 ? 0. : (double)(nn - 2) * pw[nn > 2 ? nn - 3 : 0];
-                        Rp = (double)nn * dnn - (double)(nn - 1) * dn2;
-                    } else {
-                        const double h3 = zh3(nn, mm), h2 = zh2(nn, mm), h1 = zh1(nn, mm);
-                        const double g = h2 + h3 * irp2;
-                        R = h1 * R4 + g * R2;
-                        Rp = h1 * Rp4 + g * Rp2 - 2 * h3 * irp3 * R2;
-                    }
-                    R4 = R2;
-                    Rp4 = Rp2;
-                    R2 = R;
-                    Rp2 = Rp;
-                    const double2 a = tab[zern_pair(nn, mm)];
-                    const double t1 = a.x * cm[mm] + a.y * sm[mm];
-                    S += R * t1;
-                    Sr += Rp * t1;
-                    if (mm > 0) St += R * ((double)mm * (a.y * cm[mm] - a.x * sm[mm]));
-                }
-            }
-            const double F = z - S;
-            const double Frho = -Sr / rad;
-            const double Ftheta = -St;
-            Fx = ct * Frho + (-st) * Ftheta / rho;
-            Fy = st * Frho + ct * Ftheta / rho;
+            double S, Sx, Sy;
+            zern_eval<NMAX>(tab, x, y, rad, inv_rad, S, Sx, Sy);
+            const double F = z - S;   // F = z - sum c_i Z_i ; grad F = (-dS/dx, -dS/dy, 1)
+            Fx = -Sx;
+            Fy = -Sy;
             Fz = 1.;
             const double Fp = Fx * l + Fy * m + Fz * n;
             const double delta = -F / Fp;
@@ -134,13 +153,13 @@ struct ZernOp {
             t = t + delta;
             act = fabs(delta) > PXF_TOL_1EM10;
         }
-        const double Fp = sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
+        const double iFp = 1. / sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
         c[X] = x;
         c[Y] = y;
         c[Z] = z;
-        c[UX] = Fx / Fp;
-        c[UY] = Fy / Fp;
-        c[UZ] = Fz / Fp;
+        c[UX] = Fx * iFp;
+        c[UY] = Fy * iFp;
+        c[UZ] = Fz * iFp;
         c[OPD] = c[OPD] + t * nr;  // zernsurf.f95:199 -- once, from the accumulated path length
         wm[0] = POS | NRM | (has_opd ? B(OPD) : 0u);
     }
@@ -161,13 +180,55 @@ struct ZernOpSel : ZernOp<NMAX> {
     }
 };
 
+// zernphase : zernsurf.f95:206-250.  A thin Zernike PHASE plate in the z=0 plane: one evaluation
+// (no Newton); l += dS/dx*wave, m += dS/dy*wave, n renormalised with its sign kept, opd += S*wave.
+// R opd x y l m n   W opd l m n   = 80 B/ray
+template <int NMAX>
+struct ZernPhaseOp {
+    static constexpr int MAXV = 1;
+    static constexpr unsigned RD = B(OPD) | B(X) | B(Y) | DIR;
+    static constexpr unsigned WR = B(OPD) | DIR;
+    double2 tab_arg[zern_npairs(NMAX)];
+    double rad, wave;
+    __device__ __forceinline__ double2 *lds() const
+    {
+        __shared__ double2 s_tab[zern_npairs(NMAX)];
+        return s_tab;
+    }
+    __device__ __forceinline__ void prologue() const
+    {
+        double2 *s = lds();
+        for (int i = threadIdx.x; i < zern_npairs(NMAX); i += kBlock) s[i] = tab_arg[i];
+        __syncthreads();
+    }
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+        double *c = r[0].c;
+        double S, Sx, Sy;
+        zern_eval<NMAX>(lds(), c[X], c[Y], rad, 1. / rad, S, Sx, Sy);
+        c[L] = c[L] + Sx * wave;
+        c[M] = c[M] + Sy * wave;
+        c[N] = copysign(sqrt(1. - c[L] * c[L] - c[M] * c[M]), c[N]);
+        c[OPD] = c[OPD] + S * wave;
+        wm[0] = WR;
+    }
+};
+
 // ---- host: fold (coeff, rorder, aorder) into the (n,|m|) table ----------------------------
+// `rot`: the set is evaluated at theta+rot (tracezernrot's second set, zernsurf.f95:302): by the
+// angle-addition identities  Ac cos(m(t+rot)) + As sin(m(t+rot))  =
+//   [Ac cos(m rot) + As sin(m rot)] cos(m t) + [As cos(m rot) - Ac sin(m rot)] sin(m t),
+// so a rotated set folds into the SAME table and costs the kernel nothing.  `accumulate` adds to
+// an already folded table.
 static int fold_table(const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
-                      ZernTab &tab, int &nmax)
+                      ZernTab &tab, int &nmax, double rot = 0., bool accumulate = false)
 {
     if (arrsize < 0 || (arrsize > 0 && (!coeff || !rorder || !aorder))) return PXF_EINVAL;
-    for (auto &a : tab.a) a = make_double2(0., 0.);
-    nmax = 0;
+    if (!accumulate) {
+        for (auto &a : tab.a) a = make_double2(0., 0.);
+        nmax = 0;
+    }
     const double sqrt_half_f32 = (double)sqrtf(0.5f);  // specialFunctions.f95:225: REAL*4 sqrt(0.5)
     for (int i = 0; i < arrsize; i++) {
         const int n = rorder[i], mm = aorder[i], m = mm < 0 ? -mm : mm;
@@ -176,12 +237,21 @@ static int fold_table(const double *coeff, const int32_t *rorder, const int32_t 
         if (n > nmax) nmax = n;
         const double norm = sqrt(2. * (n + 1));
         double2 &a = tab.a[zern_pair(n, m)];
+        double ac = 0., as = 0.;
         if (mm < 0)
-            a.y += coeff[i] * norm;
+            as = coeff[i] * norm;
         else if (mm > 0)
-            a.x += coeff[i] * norm;
+            ac = coeff[i] * norm;
         else
-            a.x += coeff[i] * (norm * sqrt_half_f32);
+            ac = coeff[i] * (norm * sqrt_half_f32);
+        if (rot != 0. && m > 0) {
+            const double cr = cos(m * rot), sr = sin(m * rot);
+            const double ac2 = ac * cr + as * sr, as2 = as * cr - ac * sr;
+            ac = ac2;
+            as = as2;
+        }
+        a.x += ac;
+        a.y += as;
     }
     return PXF_OK;
 }
@@ -211,6 +281,11 @@ static int dispatch_nmax(int nmax, const Cols &c, int64_t num, const uint8_t *ma
 }
 
 template <bool WOPD>
+static int run_table(const ZernTab &tab, int nmax, double *opd, double *x, double *y, double *z, const double *l,
+                     const double *m, const double *n, double *ux, double *uy, double *uz, int64_t num,
+                     double rad, double nr, const uint8_t *mask, pxf_stream_t stream);
+
+template <bool WOPD>
 static int run(double *opd, double *x, double *y, double *z, const double *l, const double *m,
                const double *n, double *ux, double *uy, double *uz, int64_t num, const double *coeff,
                const int32_t *rorder, const int32_t *aorder, int32_t arrsize, double rad, double nr,
@@ -220,6 +295,14 @@ static int run(double *opd, double *x, double *y, double *z, const double *l, co
     int nmax = 0;
     int rc = fold_table(coeff, rorder, aorder, arrsize, tab, nmax);
     if (rc != PXF_OK) return rc;
+    return run_table<WOPD>(tab, nmax, opd, x, y, z, l, m, n, ux, uy, uz, num, rad, nr, mask, stream);
+}
+
+template <bool WOPD>
+static int run_table(const ZernTab &tab, int nmax, double *opd, double *x, double *y, double *z, const double *l,
+                     const double *m, const double *n, double *ux, double *uy, double *uz, int64_t num,
+                     double rad, double nr, const uint8_t *mask, pxf_stream_t stream)
+{
     if (num < 0) return PXF_EINVAL;
     if (num == 0) return PXF_OK;
     Cols c{};
@@ -236,6 +319,24 @@ static int run(double *opd, double *x, double *y, double *z, const double *l, co
     // the folded table travels by value in the kernel arguments (<= 1152 B) and is staged into LDS
     // by each workgroup's prologue: no allocation, no copy, nothing to keep alive, graph-capturable
     return dispatch_nmax<WOPD>(nmax, c, num, mask, stream, tab, rad, nr);
+}
+
+template <int NMAX = kZernMaxN>
+static int dispatch_phase(int nmax, const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream,
+                          const ZernTab &tab, double rad, double wave)
+{
+    if constexpr (NMAX < 1) {
+        return dispatch_phase<1>(nmax, c, num, mask, stream, tab, rad, wave);
+    } else {
+        if (nmax >= NMAX || NMAX == 1) {
+            ZernPhaseOp<NMAX> op;
+            for (int i = 0; i < zern_npairs(NMAX); i++) op.tab_arg[i] = tab.a[i];
+            op.rad = rad;
+            op.wave = wave;
+            return launch_rays(c, num, mask, stream, op);
+        }
+        return dispatch_phase<NMAX - 1>(nmax, c, num, mask, stream, tab, rad, wave);
+    }
 }
 
 }  // namespace pxf
@@ -260,6 +361,39 @@ int pxf_tracezernopd(double *opd, double *x, double *y, double *z, const double 
 {
     return run<true>(opd, x, y, z, l, m, n, ux, uy, uz, num, coeff, rorder, aorder, arrsize, rad, nr, mask,
                      stream);
+}
+
+int pxf_tracezernrot(double *x, double *y, double *z, const double *l, const double *m, const double *n,
+                     double *ux, double *uy, double *uz, int64_t num, const double *coeff1,
+                     const int32_t *rorder1, const int32_t *aorder1, int32_t arrsize1, const double *coeff2,
+                     const int32_t *rorder2, const int32_t *aorder2, int32_t arrsize2, double rad, double rot,
+                     const uint8_t *mask, pxf_stream_t stream)
+{
+    ZernTab tab;
+    int nmax = 0;
+    int rc = fold_table(coeff1, rorder1, aorder1, arrsize1, tab, nmax);
+    if (rc != PXF_OK) return rc;
+    rc = fold_table(coeff2, rorder2, aorder2, arrsize2, tab, nmax, rot, true);
+    if (rc != PXF_OK) return rc;
+    return run_table<false>(tab, nmax, nullptr, x, y, z, l, m, n, ux, uy, uz, num, rad, 0., mask, stream);
+}
+
+int pxf_zernphase(double *opd, const double *x, const double *y, double *l, double *m, double *n, int64_t num,
+                  const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
+                  double rad, double wave, const uint8_t *mask, pxf_stream_t stream)
+{
+    ZernTab tab;
+    int nmax = 0;
+    int rc = fold_table(coeff, rorder, aorder, arrsize, tab, nmax);
+    if (rc != PXF_OK) return rc;
+    Cols c{};
+    c.p[OPD] = opd;
+    c.p[X] = const_cast<double *>(x);
+    c.p[Y] = const_cast<double *>(y);
+    c.p[L] = l;
+    c.p[M] = m;
+    c.p[N] = n;
+    return dispatch_phase(nmax, c, num, mask, stream, tab, rad, wave);
 }
 
 }  // extern "C"

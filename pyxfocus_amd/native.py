@@ -121,6 +121,44 @@ def paraxialy(x, y, z, l, m, n, ux, uy, uz, F, mask=None):
     _call("pxf_paraxialy", (y, m), (float(F),), mask)
 
 
+def torus(x, y, z, l, m, n, ux, uy, uz, rin, rout, mask=None):
+    fused.flush()
+    _call("pxf_torus", (x, y, z, l, m, n, ux, uy, uz), (float(rin), float(rout)), mask)
+
+
+def _f64host(a):
+    k = np.ascontiguousarray(np.asarray(a if not isinstance(a, torch.Tensor) else a.cpu(), dtype=np.float64)).reshape(-1)
+    return k, k.ctypes.data_as(_lib._DP)
+
+
+def _i32host(a):
+    k = np.ascontiguousarray(np.asarray(a if not isinstance(a, torch.Tensor) else a.cpu()), dtype=np.int32).reshape(-1)
+    return k, k.ctypes.data_as(_lib._IP)
+
+
+def conicplus(x, y, z, l, m, n, ux, uy, uz, R, K, p, mask=None):
+    pk, pp = _f64host(p)
+    fused.flush()
+    _call("pxf_conicplus", (x, y, z, l, m, n, ux, uy, uz), (float(R), float(K), pp, len(pk)), mask)
+
+
+def conicplusopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, p, nr, mask=None):
+    pk, pp = _f64host(p)
+    fused.flush()
+    _call("pxf_conicplusopd", (opd, x, y, z, l, m, n, ux, uy, uz), (float(R), float(K), pp, len(pk), float(nr)), mask)
+
+
+def legsurf(x, y, z, l, m, n, ux, uy, uz, xwidth, ywidth, order, coeff, xo, yo, mask=None):
+    _check_cols((x, y, z, l, m, n, ux, uy, uz), "pxf_legsurf")
+    ck, cp = _f64host(coeff)
+    xk, xp = _i32host(xo)
+    yk, yp = _i32host(yo)
+    if not (len(ck) == len(xk) == len(yk)):
+        raise ValueError("legsurf: coeff, xo, yo must have equal length")
+    fused.flush()
+    _call("pxf_legsurf", (x, y, l, m, n), (float(xwidth), float(ywidth), float(order), cp, xp, yp, len(ck)), mask)
+
+
 # ---- woltsurf -------------------------------------------------------------------------------
 def spocone(x, y, z, l, m, n, ux, uy, uz, R0, tg, mask=None):
     _call("pxf_spocone", (x, y, z, l, m, n, ux, uy, uz), (float(R0), float(tg)), mask)
@@ -186,6 +224,16 @@ def wssecondary(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, mask=None):
     _call("pxf_wssecondary", (x, y, z, l, m, n, ux, uy, uz), (float(alpha), float(z0), float(psi)), mask)
 
 
+def wsprimaryback(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, thick, mask=None):
+    fused.flush()
+    _call("pxf_wsprimaryback", (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (alpha, z0, psi, thick)), mask)
+
+
+def wssecondaryback(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, thick, mask=None):
+    fused.flush()
+    _call("pxf_wssecondaryback", (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (alpha, z0, psi, thick)), mask)
+
+
 def wolter_params(r0, z0, psi=1.):
     o = [C.c_double() for _ in range(3)]
     _lib.lib().pxf_wolter_params(float(r0), float(z0), float(psi), *[C.byref(v) for v in o])
@@ -214,6 +262,22 @@ def tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, 
     fused.flush()
     _call("pxf_tracezernopd", (opd, x, y, z, l, m, n, ux, uy, uz),
           (cp, rp, ap, len(ck), float(rad), float(nr)), mask)
+
+
+def zernphase(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, wave, mask=None):
+    _check_cols((opd, x, y, z, l, m, n, ux, uy, uz), "pxf_zernphase")
+    ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    fused.flush()
+    _call("pxf_zernphase", (opd, x, y, l, m, n), (cp, rp, ap, len(ck), float(rad), float(wave)), mask)
+
+
+def tracezernrot(x, y, z, l, m, n, ux, uy, uz, coeff1, rorder1, aorder1, coeff2, rorder2, aorder2, rad, rot,
+                 mask=None):
+    c1, r1, a1, c1p, r1p, a1p = _zern_tables(coeff1, rorder1, aorder1)
+    c2, r2, a2, c2p, r2p, a2p = _zern_tables(coeff2, rorder2, aorder2)
+    fused.flush()
+    _call("pxf_tracezernrot", (x, y, z, l, m, n, ux, uy, uz),
+          (c1p, r1p, a1p, len(c1), c2p, r2p, a2p, len(c2), float(rad), float(rot)), mask)
 
 
 # ---- transformationsf -----------------------------------------------------------------------
@@ -271,11 +335,14 @@ def radgratw(x, y, l, m, n, wave, dpermm, order, mask=None):
 
 surfacesf = SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd,
                             tracesphere=tracesphere, tracesphereopd=tracesphereopd, tracecyl=tracecyl,
-                            tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial, paraxialy=paraxialy)
+                            tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial, paraxialy=paraxialy,
+                            torus=torus, conicplus=conicplus, conicplusopd=conicplusopd, legsurf=legsurf)
 woltsurf = SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterprimaryopd,
                            woltersecondary=woltersecondary, spocone=spocone, woltersine=woltersine,
                            wolterprimll=wolterprimll, woltersecll=woltersecll, ellipsoidwoltll=ellipsoidwoltll,
-                           wsprimary=wsprimary, wssecondary=wssecondary)
-zernsurf = SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd)
+                           wsprimary=wsprimary, wssecondary=wssecondary, wsprimaryback=wsprimaryback,
+                           wssecondaryback=wssecondaryback)
+zernsurf = SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernphase=zernphase,
+                           tracezernrot=tracezernrot)
 transformationsf = SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
                                    radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract)

@@ -18,7 +18,8 @@ __all__ = ["flat", "zernsurf", "conic", "wolterprimary", "wolterprimarynode", "w
            "focusX", "focusY", "focusI", "zmodes", "sphere", "tanSphere", "cyl", "cylconic", "paraxial",
            "paraxialY", "spoCone", "spoPrimary", "spoSecondary", "woltersine", "primaryLL", "secondaryLL",
            "wsPrimary", "wsSecondary", "ellipsoidPrimary", "ellipsoidSecondary", "ellipsoidPrimaryLL",
-           "ellipsoidSecondaryLL"]
+           "ellipsoidSecondaryLL", "zernphase", "zernsurfrot", "conicplus", "torus", "legSurf", "wsPrimaryB",
+           "wsSecondaryB", "oapCollimate"]
 
 
 def flat(rays, ind=None, nr=None):
@@ -65,6 +66,68 @@ def zernsurf(rays, coeff, rad, rorder=None, aorder=None, nr=None):
     else:
         zern.tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, np.array(rorder), np.array(aorder), rad, nr)
     return
+
+
+def zernphase(rays, coeff, rad, wave, rorder=None, aorder=None):
+    """Standard Zernike phase surface as in ZEMAX; wavelength, radius, coeff in mm (surfaces.py:49-60)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if rorder is None:
+        rorder, aorder = zmodes(np.size(coeff))
+    zern.zernphase(opd, x, y, z, l, m, n, ux, uy, uz, coeff, np.array(rorder), np.array(aorder), rad, wave)
+    return
+
+
+def zernsurfrot(rays, coeff1, coeff2, rad, rot, rorder1=None, aorder1=None, rorder2=None, aorder2=None):
+    """Zernike surface with two Zernike sets, the second rotated by `rot` (surfaces.py:62-79)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if rorder1 is None:
+        rorder1, aorder1 = zmodes(np.size(coeff1))
+    if rorder2 is None:
+        rorder2, aorder2 = zmodes(np.size(coeff2))
+    zern.tracezernrot(x, y, z, l, m, n, ux, uy, uz, coeff1, np.array(rorder1), np.array(aorder1), coeff2,
+                      np.array(rorder2), np.array(aorder2), rad, rot)
+    return
+
+
+def conicplus(rays, R, K, p, nr=None):
+    """Conic with radius of curvature R and conic constant K plus even polynomial terms p
+    (surfaces.py:115-124)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if nr is not None:
+        surf.conicplusopd(opd, x, y, z, l, m, n, ux, uy, uz, R, K, p, nr)
+    else:
+        surf.conicplus(x, y, z, l, m, n, ux, uy, uz, R, K, p)
+    return
+
+
+def torus(rays, rin, rout):
+    """Toroidal surface: outer radius in the xy plane, inner radius orthogonal (surfaces.py:158-164)."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    surf.torus(x, y, z, l, m, n, ux, uy, uz, rin, rout)
+    return
+
+
+def legSurf(rays, xwidth, ywidth, order, coeff, xo, yo):
+    """Diffract rays from a phase surface defined by 2-D Legendre coefficients; rays must already be
+    in the x,y plane (surfaces.py:206-217)."""
+    x, y, z, l, m, n, ux, uy, uz = rays[1:]
+    surf.legsurf(x, y, z, l, m, n, ux, uy, uz, xwidth, ywidth, order, np.asarray(coeff).flatten(),
+                 np.asarray(xo).flatten(), np.asarray(yo).flatten())
+    return
+
+
+def oapCollimate(rays, efl, oapangle, nr=None):
+    """Trace rays to a collimating off-axis paraboloid; origin at the nominal OAP intersection, -z
+    toward the OAP focus, collimated beam leaves along -y.  Returns a NEW ray list in the original
+    frame (surfaces.py:126-156)."""
+    fp = efl * (1 + np.cos(oapangle)) / 2
+    coords = tran.newCoords()
+    tran.transform(rays, 0, 0, -efl, 0, 0, 0, coords=coords)
+    tran.transform(rays, 0, 0, 0, np.pi - oapangle, 0, 0, coords=coords)
+    tran.transform(rays, 0, 0, -fp, 0, 0, 0, coords=coords)
+    conic(rays, fp * 2, -1, nr=nr)
+    tran.reflect(rays)
+    return tran.applyT(rays, coords, inverse=True)
 
 
 def conic(rays, R, K, nr=None):
@@ -202,6 +265,16 @@ def _ws(fn, rays, r0, z0, psi, check):
     if check is True:
         return (x0 == x) & (y0 == y) & (zz0 == z)
     return
+
+
+def wsPrimaryB(rays, r0, z0, psi, thick, check=False):
+    """W-S primary, back surface of a substrate of thickness `thick` (surfaces.py:349-365)."""
+    return _ws(lambda *a: wolt.wsprimaryback(*a, thick), rays, r0, z0, psi, check)
+
+
+def wsSecondaryB(rays, r0, z0, psi, thick, check=False):
+    """W-S secondary, back surface (surfaces.py:385-401)."""
+    return _ws(lambda *a: wolt.wssecondaryback(*a, thick), rays, r0, z0, psi, check)
 
 
 def wsPrimary(rays, r0, z0, psi, check=False):

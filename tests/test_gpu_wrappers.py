@@ -428,8 +428,7 @@ def test_batch2_wrappers_vs_oracle(port):
     from oracle import cases
     got = {}
     for name, fn, cols, args in cases.cases(num=1500, seed=3):
-        if not any(name.startswith(p) for p in ("woltersine", "wolterprimll", "woltersecll", "ellipsoidwoltll",
-                                                  "wsprimary", "wssecondary")):
+        if name not in ("woltersine", "wolterprimll", "woltersecll", "ellipsoidwoltll", "wsprimary", "wssecondary"):
             continue
         rays = [torch.from_numpy(cols[k].copy()).cuda() for k in ALLCOLS]
         want = {k: v.copy() for k, v in cols.items()}
@@ -475,3 +474,116 @@ def test_batch2_wrappers_vs_oracle(port):
     surf.ellipsoidSecondary(rays, R0, F, S, psi)
     for k, r in zip(ALLCOLS, host(rays)):
         assert bits_equal(r, c[k]).all(), k
+
+
+def test_batch3_wrappers_vs_oracle(port):
+    """surfaces.torus / conicplus / legSurf / zernphase / zernsurfrot / wsPrimaryB / wsSecondaryB."""
+    import pyxfocus_amd.surfaces as surf
+    from oracle import cases
+    seen = set()
+    for name, fn, cols, args in cases.cases(num=1200, seed=8):
+        if name not in ("torus", "conicplus", "conicplusopd", "legsurf", "zernphase", "tracezernrot",
+                        "wsprimaryback", "wssecondaryback"):
+            continue
+        rays = [torch.from_numpy(cols[k].copy()).cuda() for k in ALLCOLS]
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, args)
+        if name == "torus":
+            surf.torus(rays, *args)
+        elif name == "conicplus":
+            surf.conicplus(rays, *args)
+        elif name == "conicplusopd":
+            surf.conicplus(rays, args[0], args[1], args[2], nr=args[3])
+        elif name == "legsurf":
+            surf.legSurf(rays, *args)
+        elif name == "zernphase":
+            cf, ro, ao, rad, wave = args
+            surf.zernphase(rays, cf, rad, wave, rorder=ro, aorder=ao)
+        elif name == "tracezernrot":
+            c1, r1, a1, c2, r2, a2, rad, rot = args
+            surf.zernsurfrot(rays, c1, c2, rad, rot, rorder1=r1, aorder1=a1, rorder2=r2, aorder2=a2)
+        elif name == "wsprimaryback":
+            surf.wsPrimaryB(rays, cases.R0, cases.Z0, args[2], args[3])
+        else:
+            surf.wsSecondaryB(rays, cases.R0, cases.Z0, args[2], args[3])
+        exact = name in ("torus", "conicplus", "conicplusopd", "legsurf")
+        tol = 2e-8 if name.startswith("ws") else 2e-11
+        for k, r in zip(ALLCOLS, host(rays)):
+            if exact:
+                assert bits_equal(r, want[k]).all(), (name, k)
+            else:
+                f = ~np.isnan(want[k])
+                assert (np.isnan(r) == np.isnan(want[k])).all() and np.abs(r[f] - want[k][f]).max() < tol, (name, k)
+        seen.add(name)
+    assert len(seen) == 8
+
+
+def test_lenses_and_oap_vs_oracle_composition(port):
+    """lenses.singlet / doublet / singletCyl and surfaces.oapCollimate: the same op sequence through
+    the oracle's native calls (lenses.py:7-91, surfaces.py:126-156)."""
+    import pyxfocus_amd.lenses as lenses
+    import pyxfocus_amd.sources as sources
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from oracle import cases
+    rng = np.random.default_rng(12)
+    n = 5000
+    c = cases._randrays(rng, n)
+    c["x"] = rng.uniform(-20, 20, n); c["y"] = rng.uniform(-20, 20, n); c["z"] = np.full(n, -5.)
+    c["l"] *= .02; c["m"] *= .02
+    c["n"] = np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    T, S = port.transformationsf, port.surfacesf
+
+    def o_transform(a, dz):
+        T.transform(*a, 0., 0., -dz, 0., 0., 0.)
+
+    # doublet AC508-250
+    w = {k: v.copy() for k, v in c.items()}
+    a = [w[k] for k in ALLCOLS[1:]]
+    r1, r2, r3, n1, n2, t1, t2 = 137.1, -111.7, 459.2, 1.5150885, 1.6437928, 7.5, 2.
+    o_transform(a, r1); S.tracesphereopd(w["opd"], *a, r1, 1.); T.refract(*a[3:], 1., n1)
+    o_transform(a, -r1 + t1 + r2); S.tracesphereopd(w["opd"], *a, r2, n1); T.refract(*a[3:], n1, n2)
+    o_transform(a, -r2 + t2 - r3); S.tracesphereopd(w["opd"], *a, r3, n2); o_transform(a, r3)
+    T.refract(*a[3:], n2, 1.); S.flatopd(*a, w["opd"], 1.)
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    lenses.AC508_250(rays)
+    for k, r in zip(ALLCOLS, host(rays)):
+        f = ~np.isnan(w[k])
+        assert (np.isnan(r) == np.isnan(w[k])).all() and np.abs(r[f] - w[k][f]).max() < 1e-11, k
+    # the doublet focuses a collimated beam near its 250 mm back focal distance
+    beam = sources.circularbeam(10., 20_000, rng="philox", seed=3)
+    lenses.AC508_250(beam)
+    dz = surf.focusI(beam)
+    assert 200. < -dz < 300. or 200. < dz < 300.
+
+    # cylindrical singlet with one flat side
+    w = {k: v.copy() for k, v in c.items()}
+    a = [w[k] for k in ALLCOLS[1:]]
+    o_transform(a, 0.); S.flatopd(*a, w["opd"], 1.); T.refract(*a[3:], 1., 1.5150885)
+    o_transform(a, 3.2 - 516.8); S.tracecylopd(w["opd"], *a, 516.8, 1.5150885); o_transform(a, 516.8)
+    T.refract(*a[3:], 1.5150885, 1.); S.flatopd(*a, w["opd"], 1.)
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    lenses.LJ1516_L2(rays)
+    for k, r in zip(ALLCOLS, host(rays)):
+        f = ~np.isnan(w[k])
+        assert (np.isnan(r) == np.isnan(w[k])).all() and np.abs(r[f] - w[k][f]).max() < 1e-11, k
+
+    # OAP: a point source at the focus (efl along -z from the nominal intersection) comes out
+    # collimated along -y; and the composite equals the same sequence through the oracle
+    ps = sources.pointsource(0.05, 50_000, rng="philox", seed=9)
+    tran.transform(ps, 0, 0, 500., 0, 0, 0)              # origin -> OAP intersection, source at z = -efl
+    w = {k: v.cpu().numpy().copy() for k, v in zip(ALLCOLS, ps)}
+    out = surf.oapCollimate(ps, 500., np.pi / 2)
+    assert out[0] is ps[0]
+    l, m, n_ = [t.cpu().numpy() for t in out[4:7]]
+    good = np.isfinite(m)
+    assert good.mean() > .99 and np.abs(np.abs(m[good]) - 1.).max() < 1e-9 and np.abs(l[good]).max() < 1e-7
+    a = [w[k] for k in ALLCOLS[1:]]
+    fp = 500. * (1 + np.cos(np.pi / 2)) / 2
+    T.transform(*a, 0., 0., 500., 0., 0., 0.)
+    T.transform(*a, 0., 0., 0., -(np.pi - np.pi / 2), 0., 0.)
+    T.transform(*a, 0., 0., fp, 0., 0., 0.)
+    S.conic(*a, fp * 2, -1.)
+    T.reflect(*a[3:])
+    for k, r in zip(ALLCOLS[1:], host(ps)[1:]):          # ps itself was traced in place (local frame)
+        assert bits_equal(r, w[k]).all(), k

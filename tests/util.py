@@ -9,7 +9,8 @@ BITWISE = {"surfacesf.flat", "surfacesf.flatopd", "surfacesf.conic", "surfacesf.
            "transformationsf.transform", "transformationsf.itransform", "transformationsf.reflect",
            "woltsurf.spocone", "transformationsf.grat", "surfacesf.tracesphere", "surfacesf.tracesphereopd",
            "surfacesf.tracecyl", "surfacesf.tracecylopd", "surfacesf.cylconic", "surfacesf.paraxial",
-           "surfacesf.paraxialy"}
+           "surfacesf.paraxialy", "surfacesf.torus", "surfacesf.conicplus", "surfacesf.conicplusopd",
+           "surfacesf.legsurf"}
 # tolerance-parity functions: |gpu - ref| <= atol + rtol*|ref| + cond/|ref| per column.
 # radgrat: l, m agree to an ulp; n = sn*sqrt(1-l^2-m^2) is ill-conditioned at grazing incidence
 # (|n| -> 0): a 1-ulp (1.1e-16) difference in m moves n by 1.1e-16/|n|, hence the cond term on n.
@@ -24,7 +25,9 @@ TOL = {"transformationsf.radgrat": (1e-14, 1e-13, {"n": 3e-16}),
        # W-S: the reference stops at |step| <= 1.e-8 mm and its iteration converges only linearly, so
        # two evaluations that differ in the last bits may stop one step apart: agreement is to the
        # algorithm's own convergence tolerance (positions), normals follow to ~1e-9
-       "woltsurf.wsprimary": (2e-8, 1e-13, {}), "woltsurf.wssecondary": (2e-8, 1e-13, {})}
+       "woltsurf.wsprimary": (2e-8, 1e-13, {}), "woltsurf.wssecondary": (2e-8, 1e-13, {}),
+       "woltsurf.wsprimaryback": (2e-8, 1e-13, {}), "woltsurf.wssecondaryback": (2e-8, 1e-13, {}),
+       "zernsurf.zernphase": (1e-13, 1e-12, {}), "zernsurf.tracezernrot": (2e-11, 1e-12, {})}
 
 
 def bits_equal(a, b):
