@@ -74,11 +74,14 @@ __device__ __forceinline__ void load_col(const double *p, int64_t v, double (&r)
 {
     if constexpr (V == 1) {
         r[0] = NT ? __builtin_nontemporal_load(p + v) : p[v];
-    } else {
-        const d2_t *q = reinterpret_cast<const d2_t *>(p + 2 * v);
-        const d2_t t = NT ? __builtin_nontemporal_load(q) : *q;
-        r[0] = t.x;
-        r[1] = t.y;
+    } else {  // V = 2, 4: V/2 consecutive 16-byte accesses
+        const d2_t *q = reinterpret_cast<const d2_t *>(p + V * v);
+#pragma unroll
+        for (int h = 0; h < V / 2; h++) {
+            const d2_t t = NT ? __builtin_nontemporal_load(q + h) : q[h];
+            r[2 * h] = t.x;
+            r[2 * h + 1] = t.y;
+        }
     }
 }
 
@@ -93,17 +96,21 @@ __device__ __forceinline__ void store_col(double *p, int64_t v, const double (&r
                 p[v] = r[0];
         }
     } else {
-        if (w[0] && w[1]) {
-            d2_t t;
-            t.x = r[0];
-            t.y = r[1];
-            if (NT)
-                __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(p + 2 * v));
-            else
-                *reinterpret_cast<d2_t *>(p + 2 * v) = t;
-        } else {
-            if (w[0]) p[2 * v] = r[0];
-            if (w[1]) p[2 * v + 1] = r[1];
+#pragma unroll
+        for (int h = 0; h < V / 2; h++) {
+            double *q = p + V * v + 2 * h;
+            if (w[2 * h] && w[2 * h + 1]) {
+                d2_t t;
+                t.x = r[2 * h];
+                t.y = r[2 * h + 1];
+                if (NT)
+                    __builtin_nontemporal_store(t, reinterpret_cast<d2_t *>(q));
+                else
+                    *reinterpret_cast<d2_t *>(q) = t;
+            } else {
+                if (w[2 * h]) q[0] = r[2 * h];
+                if (w[2 * h + 1]) q[1] = r[2 * h + 1];
+            }
         }
     }
 }

@@ -246,3 +246,76 @@ def test_full_size_1e9_rays_properties(port):
         for k, u in zip(ALLCOLS, got):
             # everything up to radgrat is bit-identical; radgrat is 1e-14-level, then propagated ~8 m
             assert np.abs(u - c[k]).max() < 5e-10, (k, np.abs(u - c[k]).max())
+
+
+def test_streams_and_graph_capture(port):
+    """Every launch goes to torch's CURRENT stream (no implicit sync, nothing allocated by the
+    library), so a trace can run on a side stream and be captured into a HIP graph and replayed."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(41)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    c = cases.annulus_rays(rng, 300_000, rin, rout, 0.)
+    want = {k: v.copy() for k, v in c.items()}
+    cases.chain_config2(port, want)
+
+    def trace(r):
+        tran.transform(r, 0, 0, -(cases.Z0 + 2 * cases.LMIR), 0, 0, 0)
+        surf.wolterprimary(r, cases.R0, cases.Z0)
+        tran.reflect(r)
+        surf.woltersecondary(r, cases.R0, cases.Z0)
+        tran.reflect(r)
+        surf.flat(r)
+
+    # side stream
+    side = torch.cuda.Stream()
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        trace(rays)
+    side.synchronize()
+    for k, r in zip(ALLCOLS, rays):
+        assert bits_equal(r.cpu().numpy(), want[k]).all(), k
+    # graph capture: eager calls and a fused program, replayed on fresh inputs
+    static = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            tran.transform(static, 0, 0, -(cases.Z0 + 2 * cases.LMIR), 0, 0, 0)
+            with pxf.fused():
+                surf.wolterprimary(static, cases.R0, cases.Z0)
+                tran.reflect(static)
+                surf.woltersecondary(static, cases.R0, cases.Z0)
+                tran.reflect(static)
+            surf.flat(static)
+    torch.cuda.current_stream().wait_stream(cap)
+    for rep in range(2):
+        for k, t in zip(ALLCOLS, static):
+            t.copy_(torch.from_numpy(c[k]))
+        g.replay()
+        torch.cuda.synchronize()
+        for k, r in zip(ALLCOLS, static):
+            assert bits_equal(r.cpu().numpy(), want[k]).all(), (rep, k)
+
+
+def test_argument_validation_through_python_layer():
+    from pyxfocus_amd import _lib, native
+    import pyxfocus_amd.surfaces as surf
+    rays = [torch.zeros(16, dtype=torch.float64, device="cuda") for _ in range(10)]
+    with pytest.raises(ValueError, match="differ in length"):
+        native.surfacesf.flat(*rays[1:9], torch.zeros(15, dtype=torch.float64, device="cuda"))
+    with pytest.raises(TypeError, match="mask"):
+        native.surfacesf.flat(*rays[1:], mask=torch.zeros(16, dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        native.surfacesf.flat(*rays[1:], mask=torch.zeros(15, dtype=torch.bool, device="cuda"))
+    with pytest.raises(_lib.PxfError, match="range"):
+        surf.zernsurf(rays, [1., 1.], 50., rorder=[2, 40], aorder=[0, 0])
+    with pytest.raises(_lib.PxfError, match="invalid"):
+        surf.zernsurf(rays, [1.], 50., rorder=[2], aorder=[1])           # n - |m| odd: not a Zernike term
+    with pytest.raises(IndexError):
+        import pyxfocus_amd.transformations as tran
+        tran.reflect(rays, ind=np.array([99]))
