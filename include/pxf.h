@@ -389,6 +389,26 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
 int pxf_program_plan(const pxf_op_t *ops, int32_t nops, uint32_t *load_mask, uint32_t *store_mask,
                      int32_t *dropped);
 
+/* ---- segmented bundles (multi-shell optics in one launch) ------------------------------------------
+ * A bundle made of `nseg` contiguous segments of `rays_per_seg` rays (mirror shells, modules, ...)
+ * that run the SAME operation sequence with DIFFERENT parameters.  The reference loops over shells
+ * in Python (examples/arcus/sector.py:556-626); here the per-segment parameter blocks sit in a
+ * device table, each workgroup stages the blocks of the segments its rays belong to in LDS, and the
+ * whole bundle is traced by one launch.
+ *   pxf_program_params        host: the internal parameter block (9 doubles per LIVE op, in plan
+ *                             order) the planner derives for one op list -> build the table by calling
+ *                             it once per segment; *nlive = number of live ops (same for every segment)
+ *   pxf_program_run_segments  `ops` gives the sequence (codes, masks, aux; its a[] is ignored),
+ *                             seg_params_dev = device double[nseg][nlive][9]; num == nseg*rays_per_seg,
+ *                             rays_per_seg even and >= 172; columns 16-byte aligned
+ *   pxf_source_segments       device source whose (p0..p3) come per segment from device double[nseg][4] */
+int pxf_program_params(const pxf_op_t *ops, int32_t nops, double *params_out, int32_t *nlive);
+int pxf_program_run_segments(const pxf_op_t *ops, int32_t nops, const double *seg_params_dev, int32_t nseg,
+                             int64_t rays_per_seg, double *const *cols, int64_t num, pxf_stream_t stream);
+int pxf_source_segments(int32_t kind, double *const *cols, int64_t num, const double *seg_params_dev,
+                        int32_t nseg, int64_t rays_per_seg, uint64_t seed, uint64_t first_index,
+                        pxf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

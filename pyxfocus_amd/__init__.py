@@ -13,4 +13,4 @@ include/pxf.h (pyxfocus_amd/csrc/libpxf_hip.so).  There is no CPU fallback.
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401  (does not load the shared library until first use)
-from ._fused import flush, fused  # noqa: E402,F401
+from ._fused import compile_segments, flush, fused  # noqa: E402,F401

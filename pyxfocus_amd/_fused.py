@@ -141,6 +141,72 @@ class fused:
         return False
 
 
+class SegmentedProgram:
+    """A trace compiled for a bundle of equal contiguous SEGMENTS (mirror shells, modules ...): the
+    same call sequence with per-segment parameters, executed by ONE launch (pxf_program_run_segments;
+    parameter blocks staged per workgroup in LDS).  Build with `compile_segments`, then `.run()` as
+    often as needed (e.g. after refilling the bundle from a segmented source)."""
+
+    def __init__(self, rays, rays_per_seg, ops, table, keep):
+        self.rays = list(rays)
+        self.rps = int(rays_per_seg)
+        self.ops = ops                  # ctypes array of PxfOp (codes, masks, aux)
+        self.table = table              # device tensor [nseg, nlive, 9]
+        self.keep = keep
+
+    def run(self):
+        flush()
+        dev = self.rays[1].device
+        ptrs = (C.c_void_p * 10)(*[t.data_ptr() for t in self.rays])
+        with torch.cuda.device(dev):
+            rc = _lib.lib().pxf_program_run_segments(self.ops, len(self.ops), self.table.data_ptr(),
+                                                     self.table.shape[0], self.rps, ptrs, self.rays[1].shape[0],
+                                                     torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "pxf_program_run_segments")
+
+
+def compile_segments(rays, rays_per_seg, fn, params):
+    """Record `fn(segment_view, *params[s])` for every segment s WITHOUT launching anything, check that
+    all segments issue the same operation sequence, and return a SegmentedProgram for the whole
+    bundle.  `rays` is the full ten-column bundle, segment s = rays[s*rays_per_seg:(s+1)*rays_per_seg].
+    `fn` may use any fusable call (see `fused`), including `ind=` masks only if they are whole-bundle
+    masks (not supported per segment)."""
+    import numpy as np
+    num = rays[1].shape[0]
+    nseg = len(params)
+    rps = int(rays_per_seg)
+    if nseg * rps != num:
+        raise ValueError("compile_segments: len(params) * rays_per_seg must equal the bundle length")
+    h = _lib.lib()
+    rows, codes0, ops0 = [], None, None
+    if getattr(_tls, "rec", None) is not None:
+        raise _lib.PxfError("compile_segments cannot be called inside a fused() block")
+    for s_, par in enumerate(params):
+        view = [c[s_ * rps:(s_ + 1) * rps] for c in rays]
+        rec = _Recorder()
+        _tls.rec = rec
+        try:
+            fn(view, *par)
+        finally:
+            _tls.rec = None
+        if rec.launches or not rec.ops:
+            raise _lib.PxfError("compile_segments: the segment function issued a call that cannot be fused")
+        if any(o.mask or o.aux for o in rec.ops):
+            raise _lib.PxfError("compile_segments: ind= masks / per-ray columns are not supported per segment")
+        arr = (PxfOp * len(rec.ops))(*rec.ops)
+        out = (C.c_double * (9 * len(rec.ops)))()
+        nl = C.c_int32()
+        _lib.check(h.pxf_program_params(arr, len(rec.ops), out, C.byref(nl)), "pxf_program_params")
+        codes = [o.code for o in rec.ops]
+        if codes0 is None:
+            codes0, ops0, nlive = codes, arr, nl.value
+        elif codes != codes0 or nl.value != nlive:
+            raise _lib.PxfError("compile_segments: segment %d issues a different operation sequence" % s_)
+        rows.append(np.frombuffer(out, dtype=np.float64, count=9 * nlive).copy())
+    table = torch.from_numpy(np.stack(rows).reshape(nseg, nlive, 9)).to(rays[1].device)
+    return SegmentedProgram(rays, rps, ops0, table, None)
+
+
 def plan(ops):
     """(load_mask, store_mask, dropped) the planner derives for a list of PxfOp (tests/reports)."""
     arr = (PxfOp * len(ops))(*ops)

@@ -83,6 +83,9 @@ _SIGS = {
     "pxf_kth_values": [_P, _i64, C.POINTER(C.c_int64), _i32, _P, _P, _P],
     "pxf_source": [_i32, _PP, _i64, _d, _d, _d, _d, _u64, _u64, _P],
     "pxf_program_run": [_P, _i32, _PP, _i64, _P],
+    "pxf_program_params": [_P, _i32, _DP, C.POINTER(C.c_int32)],
+    "pxf_program_run_segments": [_P, _i32, _P, _i32, _i64, _PP, _i64, _P],
+    "pxf_source_segments": [_i32, _PP, _i64, _P, _i32, _i64, _u64, _u64, _P],
     "pxf_program_plan": [_P, _i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)],
 }
 _RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,

@@ -42,6 +42,64 @@ __device__ __forceinline__ void run_op(const OP &o, Ray (&r)[V], const bool (&se
     o.template apply<V>(r, sel, wm);
 }
 
+// One operation on the V rays of a thread.  `P` points at the op's nine doubles: the kernel
+// arguments for an ordinary program (wave-uniform -> scalar loads), or the workgroup's LDS copy of
+// the ray's SEGMENT parameters for a segmented program.
+template <int V, bool NT>
+__device__ __forceinline__ void exec_op(int code, int flags, const double *__restrict__ P,
+                                        const double *__restrict__ aux, int64_t vv, Ray (&r)[V],
+                                        const bool (&sel)[V])
+{
+    switch (code) {
+        case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
+        case PXF_OP_FLATOPD: run_op(FlatOp<true>{P[0]}, r, sel); break;
+        case PXF_OP_CONIC: run_op(ConicOp<false>{P[0], P[1], 0.}, r, sel); break;
+        case PXF_OP_CONICOPD: run_op(ConicOp<true>{P[0], P[1], P[2]}, r, sel); break;
+        case PXF_OP_WOLTERPRIMARY: run_op(WolterPrimaryOp<false>{P[0], P[1], P[2], 0.}, r, sel); break;
+        case PXF_OP_WOLTERPRIMARYOPD:
+            run_op(WolterPrimaryOp<true>{P[0], P[1], P[2], P[3]}, r, sel);
+            break;
+        case PXF_OP_WOLTERSECONDARY: run_op(WolterSecondaryOp{P[0], P[1], P[2]}, r, sel); break;
+        case PXF_OP_TRANSFORM:
+            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            break;
+        case PXF_OP_ITRANSFORM:
+            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            break;
+        case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
+        case PXF_OP_RADGRAT: run_op(RadgratOp<false>{P[0], P[1], P[2], P[3], P[4]}, r, sel); break;
+        case PXF_OP_RADGRATW: {
+            double t[V];
+            load_col<V, NT>(aux, vv, t);
+#pragma unroll
+            for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
+            run_op(RadgratOp<true>{P[0], P[1], 0., P[3], P[4]}, r, sel);
+            break;
+        }
+        case PXF_OP_SPOCONE: run_op(SpoConeOp{P[0], P[1], P[2], P[3]}, r, sel); break;
+        case PXF_OP_SPHERE: run_op(SphereCylOp<false, false>{P[0], 0.}, r, sel); break;
+        case PXF_OP_SPHEREOPD: run_op(SphereCylOp<true, false>{P[0], P[1]}, r, sel); break;
+        case PXF_OP_CYL: run_op(SphereCylOp<false, true>{P[0], 0.}, r, sel); break;
+        case PXF_OP_CYLOPD: run_op(SphereCylOp<true, true>{P[0], P[1]}, r, sel); break;
+        case PXF_OP_CYLCONIC: run_op(CylConicOp{P[0], P[1]}, r, sel); break;
+        case PXF_OP_PARAXIAL: run_op(ParaxialOp<false>{P[0]}, r, sel); break;
+        case PXF_OP_PARAXIALY: run_op(ParaxialOp<true>{P[0]}, r, sel); break;
+        case PXF_OP_GRAT:
+            if (aux) {
+                double t[V];
+                load_col<V, NT>(aux, vv, t);
+#pragma unroll
+                for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
+                run_op(GratOp<true>{P[0], 0.}, r, sel);
+            } else {
+                run_op(GratOp<false>{P[0], P[1]}, r, sel);
+            }
+            break;
+        case PXF_OP_REFRACT: run_op(RefractOp{P[0], P[1]}, r, sel); break;
+        default: break;
+    }
+}
+
 // ANYMASK=false instantiations carry no per-op mask code (no saved copy of the ray -> fewer VGPRs)
 template <int V, bool NT, bool ANYMASK>
 __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
@@ -74,54 +132,7 @@ __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, 
 #pragma unroll
                 for (int k = 0; k < V; k++) sel[k] = true;
             }
-            switch (o.code) {
-                case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
-                case PXF_OP_FLATOPD: run_op(FlatOp<true>{o.p[0]}, r, sel); break;
-                case PXF_OP_CONIC: run_op(ConicOp<false>{o.p[0], o.p[1], 0.}, r, sel); break;
-                case PXF_OP_CONICOPD: run_op(ConicOp<true>{o.p[0], o.p[1], o.p[2]}, r, sel); break;
-                case PXF_OP_WOLTERPRIMARY: run_op(WolterPrimaryOp<false>{o.p[0], o.p[1], o.p[2], 0.}, r, sel); break;
-                case PXF_OP_WOLTERPRIMARYOPD:
-                    run_op(WolterPrimaryOp<true>{o.p[0], o.p[1], o.p[2], o.p[3]}, r, sel);
-                    break;
-                case PXF_OP_WOLTERSECONDARY: run_op(WolterSecondaryOp{o.p[0], o.p[1], o.p[2]}, r, sel); break;
-                case PXF_OP_TRANSFORM:
-                    run_op(TransformOp<false>{o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.flags}, r, sel);
-                    break;
-                case PXF_OP_ITRANSFORM:
-                    run_op(TransformOp<true>{o.p[0], o.p[1], o.p[2], o.p[3], o.p[4], o.p[5], o.p[6], o.p[7], o.p[8], o.flags}, r, sel);
-                    break;
-                case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
-                case PXF_OP_RADGRAT: run_op(RadgratOp<false>{o.p[0], o.p[1], o.p[2], o.p[3], o.p[4]}, r, sel); break;
-                case PXF_OP_RADGRATW: {
-                    double t[V];
-                    load_col<V, NT>(o.aux, vv, t);
-#pragma unroll
-                    for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
-                    run_op(RadgratOp<true>{o.p[0], o.p[1], 0., o.p[3], o.p[4]}, r, sel);
-                    break;
-                }
-                case PXF_OP_SPOCONE: run_op(SpoConeOp{o.p[0], o.p[1], o.p[2], o.p[3]}, r, sel); break;
-                case PXF_OP_SPHERE: run_op(SphereCylOp<false, false>{o.p[0], 0.}, r, sel); break;
-                case PXF_OP_SPHEREOPD: run_op(SphereCylOp<true, false>{o.p[0], o.p[1]}, r, sel); break;
-                case PXF_OP_CYL: run_op(SphereCylOp<false, true>{o.p[0], 0.}, r, sel); break;
-                case PXF_OP_CYLOPD: run_op(SphereCylOp<true, true>{o.p[0], o.p[1]}, r, sel); break;
-                case PXF_OP_CYLCONIC: run_op(CylConicOp{o.p[0], o.p[1]}, r, sel); break;
-                case PXF_OP_PARAXIAL: run_op(ParaxialOp<false>{o.p[0]}, r, sel); break;
-                case PXF_OP_PARAXIALY: run_op(ParaxialOp<true>{o.p[0]}, r, sel); break;
-                case PXF_OP_GRAT:
-                    if (o.aux) {
-                        double t[V];
-                        load_col<V, NT>(o.aux, vv, t);
-#pragma unroll
-                        for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
-                        run_op(GratOp<true>{o.p[0], 0.}, r, sel);
-                    } else {
-                        run_op(GratOp<false>{o.p[0], o.p[1]}, r, sel);
-                    }
-                    break;
-                case PXF_OP_REFRACT: run_op(RefractOp{o.p[0], o.p[1]}, r, sel); break;
-                default: break;
-            }
+            exec_op<V, NT>(o.code, o.flags, o.p, o.aux, vv, r, sel);
             if (masked) {  // unselected rays keep every register
 #pragma unroll
                 for (int k = 0; k < V; k++)
@@ -139,6 +150,91 @@ __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, 
                     w[k] = true;
                 }
                 store_col<V, NT>(c.p[col], vv, t, w);
+            }
+        }
+    }
+}
+
+// ---- segmented program --------------------------------------------------------------------
+// One launch for a bundle made of contiguous SEGMENTS of `rps` rays (mirror shells, modules ...)
+// that run the same operation sequence with different parameters -- the reference does this as
+// a Python loop over shells (examples/arcus/sector.py:556).  The per-segment parameter blocks live
+// in a device table [nseg][nops][9]; each workgroup stages the blocks of the (at most
+// kMaxSegPerBlock) segments its 256*V rays fall into in LDS, and every ray then reads its own
+// segment's block (all lanes of a wave normally share one address: LDS broadcast).
+constexpr int kMaxSegPerBlock = 4;
+
+struct SegInfo {
+    const double *table;  // device [nseg][nops][9]
+    int64_t rps;          // rays per segment (even)
+    int nseg;
+};
+
+template <bool NT, bool ANYMASK>
+__global__ __launch_bounds__(kBlock) void program_seg_kernel(Cols c, int64_t nvec, Program pg, SegInfo sg)
+{
+    constexpr int V = 2;
+    __shared__ double s_par[kMaxSegPerBlock][kMaxOps][9];
+    const int64_t ntiles = (nvec + kBlock - 1) / kBlock;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t v0 = tile * kBlock;
+        const int64_t vlast = (v0 + kBlock - 1 < nvec ? v0 + kBlock - 1 : nvec - 1);
+        const int64_t seg0 = (v0 * V) / sg.rps, seg1 = (vlast * V + V - 1) / sg.rps;
+        const int nsb = (int)(seg1 - seg0 + 1);
+        const int per = pg.nops * 9;
+        __syncthreads();  // previous tile's readers are done
+        for (int i = threadIdx.x; i < nsb * per; i += kBlock) {
+            const int sb = i / per, q = i - sb * per;
+            s_par[sb][q / 9][q % 9] = sg.table[(seg0 + sb) * per + q];
+        }
+        __syncthreads();
+        const int64_t vv = v0 + threadIdx.x;
+        if (vv < nvec) {
+            const int sb = (int)((vv * V) / sg.rps - seg0);
+            Ray r[V];
+#pragma unroll
+            for (int col = 0; col < 10; col++) {
+                if (pg.load & B(col)) {
+                    double t[V];
+                    load_col<V, NT>(c.p[col], vv, t);
+#pragma unroll
+                    for (int k = 0; k < V; k++) r[k].c[col] = t[k];
+                }
+            }
+            for (int i = 0; i < pg.nops; i++) {
+                const ProgOp &o = pg.op[i];
+                bool sel[V];
+                Ray keep[ANYMASK ? V : 1];
+                const bool masked = ANYMASK && o.mask != nullptr;
+                if (masked) {
+#pragma unroll
+                    for (int k = 0; k < V; k++) {
+                        sel[k] = o.mask[vv * V + k] != 0;
+                        keep[k] = r[k];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; k++) sel[k] = true;
+                }
+                exec_op<V, NT>(o.code, o.flags, &s_par[sb][i][0], o.aux, vv, r, sel);
+                if (masked) {
+#pragma unroll
+                    for (int k = 0; k < V; k++)
+                        if (!sel[k]) r[k] = keep[k];
+                }
+            }
+#pragma unroll
+            for (int col = 0; col < 10; col++) {
+                if (pg.store & B(col)) {
+                    double t[V];
+                    bool w[V];
+#pragma unroll
+                    for (int k = 0; k < V; k++) {
+                        t[k] = r[k].c[col];
+                        w[k] = true;
+                    }
+                    store_col<V, NT>(c.p[col], vv, t, w);
+                }
             }
         }
     }
@@ -389,6 +485,58 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
     if (done < num) PXF_PLAUNCH_V(1, done, num - done);
 #undef PXF_PLAUNCH_V
 #undef PXF_PLAUNCH
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_program_params(const pxf_op_t *ops, int32_t nops, double *params_out, int32_t *nlive)
+{
+    Program pg{};
+    int rc = plan_program(ops, nops, pg, nullptr);
+    if (rc != PXF_OK) return rc;
+    if (!params_out || !nlive) return PXF_EINVAL;
+    for (int i = 0; i < pg.nops; i++)
+        for (int k = 0; k < 9; k++) params_out[i * 9 + k] = pg.op[i].p[k];
+    *nlive = pg.nops;
+    return PXF_OK;
+}
+
+int pxf_program_run_segments(const pxf_op_t *ops, int32_t nops, const double *seg_params_dev, int32_t nseg,
+                             int64_t rays_per_seg, double *const *cols, int64_t num, pxf_stream_t stream)
+{
+    Program pg{};
+    int rc = plan_program(ops, nops, pg, nullptr);
+    if (rc != PXF_OK) return rc;
+    if (num < 0 || !cols || nseg < 1 || !seg_params_dev) return PXF_EINVAL;
+    // every workgroup (512 rays) must span at most kMaxSegPerBlock segments; ray pairs stay in one segment
+    if (rays_per_seg < 2 || (rays_per_seg & 1) || rays_per_seg * (kMaxSegPerBlock - 1) < 2 * kBlock) return PXF_ERANGE;
+    if (num != (int64_t)nseg * rays_per_seg) return PXF_EINVAL;
+    if (num == 0 || pg.nops == 0) return PXF_OK;
+    Cols c{};
+    for (int col = 0; col < 10; col++) {
+        c.p[col] = cols[col];
+        if ((pg.load | pg.store) & B(col)) {
+            if (!cols[col]) return PXF_EINVAL;
+            if ((uintptr_t)cols[col] & 15) return PXF_EINVAL;  // segmented bundles are whole, aligned bundles
+        }
+    }
+    bool anymask = false;
+    for (int i = 0; i < pg.nops; i++) {
+        anymask |= pg.op[i].mask != nullptr;
+        if (pg.op[i].aux && ((uintptr_t)pg.op[i].aux & 15)) return PXF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const bool nt = use_nt(num);
+    const int64_t nvec = num / 2;
+    SegInfo sg{seg_params_dev, rays_per_seg, nseg};
+    const dim3 grid(grid_for(nvec)), block(kBlock);
+    if (anymask) {
+        if (nt) hipLaunchKernelGGL((program_seg_kernel<true, true>), grid, block, 0, s, c, nvec, pg, sg);
+        else hipLaunchKernelGGL((program_seg_kernel<false, true>), grid, block, 0, s, c, nvec, pg, sg);
+    } else {
+        if (nt) hipLaunchKernelGGL((program_seg_kernel<true, false>), grid, block, 0, s, c, nvec, pg, sg);
+        else hipLaunchKernelGGL((program_seg_kernel<false, false>), grid, block, 0, s, c, nvec, pg, sg);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }

@@ -109,6 +109,49 @@ __global__ __launch_bounds__(kBlock) void source_kernel(Cols cols, int64_t first
     }
 }
 
+// segmented source: ray i belongs to segment i / rps and takes its four parameters from a device
+// table [nseg][4] (consecutive rays read the same 32 bytes: one L1 line per wave)
+template <int KIND, bool NT>
+__global__ __launch_bounds__(kBlock) void source_seg_kernel(Cols cols, int64_t nvec, SrcParams q,
+                                                            const double *__restrict__ table, int64_t rps)
+{
+    constexpr int V = 2;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const double *t4 = table + ((v * V) / rps) * 4;
+        SrcParams qq = q;
+        qq.p0 = t4[0];
+        qq.p1 = t4[1];
+        qq.p2 = t4[2];
+        qq.p3 = t4[3];
+        double r[V][10];
+#pragma unroll
+        for (int k = 0; k < V; k++) make_ray<KIND>(qq, q.first + (uint64_t)(v * V + k), r[k]);
+#pragma unroll
+        for (int col = 0; col < 10; col++) {
+            double t[V];
+            bool w[V];
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                t[k] = r[k][col];
+                w[k] = true;
+            }
+            store_col<V, NT>(cols.p[col], v, t, w);
+        }
+    }
+}
+
+template <int KIND>
+static void launch_seg_kind(const Cols &c, int64_t num, const SrcParams &q, const double *table, int64_t rps,
+                            hipStream_t s)
+{
+    const int64_t nvec = num / 2;
+    if (use_nt(num))
+        hipLaunchKernelGGL((source_seg_kernel<KIND, true>), dim3(grid_for(nvec)), dim3(kBlock), 0, s, c, nvec, q, table, rps);
+    else
+        hipLaunchKernelGGL((source_seg_kernel<KIND, false>), dim3(grid_for(nvec)), dim3(kBlock), 0, s, c, nvec, q, table, rps);
+}
+
 template <int KIND>
 static void launch_kind(const Cols &c, bool aligned, int64_t num, const SrcParams &q, hipStream_t s)
 {
@@ -153,6 +196,31 @@ extern "C" int pxf_source(int32_t kind, double *const *cols, int64_t num, double
         case PXF_SRC_ANNULUS: launch_kind<PXF_SRC_ANNULUS>(c, aligned, num, q, s); break;
         case PXF_SRC_SUBANNULUS: launch_kind<PXF_SRC_SUBANNULUS>(c, aligned, num, q, s); break;
         case PXF_SRC_RECTBEAM: launch_kind<PXF_SRC_RECTBEAM>(c, aligned, num, q, s); break;
+        default: return PXF_EINVAL;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+extern "C" int pxf_source_segments(int32_t kind, double *const *cols, int64_t num, const double *seg_params_dev,
+                                   int32_t nseg, int64_t rays_per_seg, uint64_t seed, uint64_t first_index,
+                                   pxf_stream_t stream)
+{
+    if (num < 0 || !cols || !seg_params_dev || nseg < 1) return PXF_EINVAL;
+    if (rays_per_seg < 2 || (rays_per_seg & 1) || num != (int64_t)nseg * rays_per_seg) return PXF_EINVAL;
+    Cols c{};
+    for (int k = 0; k < 10; k++) {
+        if (!cols[k] || ((uintptr_t)cols[k] & 15)) return PXF_EINVAL;
+        c.p[k] = cols[k];
+    }
+    SrcParams q{0., 0., 0., 0., seed, first_index};
+    hipStream_t s = (hipStream_t)stream;
+    switch (kind) {
+        case PXF_SRC_POINTSOURCE: launch_seg_kind<PXF_SRC_POINTSOURCE>(c, num, q, seg_params_dev, rays_per_seg, s); break;
+        case PXF_SRC_CIRCULARBEAM: launch_seg_kind<PXF_SRC_CIRCULARBEAM>(c, num, q, seg_params_dev, rays_per_seg, s); break;
+        case PXF_SRC_ANNULUS: launch_seg_kind<PXF_SRC_ANNULUS>(c, num, q, seg_params_dev, rays_per_seg, s); break;
+        case PXF_SRC_SUBANNULUS: launch_seg_kind<PXF_SRC_SUBANNULUS>(c, num, q, seg_params_dev, rays_per_seg, s); break;
+        case PXF_SRC_RECTBEAM: launch_seg_kind<PXF_SRC_RECTBEAM>(c, num, q, seg_params_dev, rays_per_seg, s); break;
         default: return PXF_EINVAL;
     }
     hipError_t e = hipGetLastError();

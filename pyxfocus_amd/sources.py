@@ -68,6 +68,26 @@ def _philox(kind, num, p, seed, first_index, device, out=None):
     return rays
 
 
+def segments(kind, params, rays_per_seg, out, seed=0, first_index=0):
+    """Fill a whole multi-segment bundle in ONE launch: segment s (rays [s*rays_per_seg,
+    (s+1)*rays_per_seg) of `out`) is a `kind` source ("annulus", "subannulus", "pointsource",
+    "circularbeam", "rectbeam") with parameters params[s] = (p0, p1, p2, p3) as documented for
+    pxf_source (e.g. subannulus: rin, rout, dphi, zhat).  Device Philox keyed on the global ray index."""
+    rays = list(out)
+    num = rays[0].shape[0]
+    tab = torch.as_tensor(np.asarray(params, dtype=np.float64).reshape(-1, 4)).to(rays[0].device)
+    if tab.shape[0] * int(rays_per_seg) != num:
+        raise ValueError("len(params) * rays_per_seg must equal the bundle length")
+    arr = (C.c_void_p * 10)(*[r.data_ptr() for r in rays])
+    dev = rays[0].device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_source_segments(_lib.SRC_KINDS[kind], arr, num, tab.data_ptr(), tab.shape[0],
+                                            int(rays_per_seg), int(seed) & (2 ** 64 - 1), int(first_index),
+                                            torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "pxf_source_segments")
+    return rays
+
+
 def pointsource(ang, num, device=None, rng="numpy", seed=0, first_index=0, out=None):
     """Point source with half-angle divergence `ang`; rays point in +z (sources.py:20-53)."""
     if rng == "philox":

@@ -189,3 +189,59 @@ def test_fused_batch1_ops_equal_eager():
         program(b)
     assert rec.launches == 1 and rec.fused_ops == 14
     same(a, b)
+
+
+def test_segmented_program_equals_per_segment_loop():
+    """Multi-shell bundle: one launch with per-segment parameters (LDS-staged) == a loop of per-shell
+    fused programs == a loop of plain calls, bit for bit; segmented source == per-shell sources."""
+    import math
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.sources as sources
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from pyxfocus_amd import conicsolve as con
+    F, lmir = 12e3, 50.
+    shells = [(320. + .775 * i, math.sqrt(F * F - (320. + .775 * i) ** 2), .01 * (i % 7 - 3), .15) for i in range(37)]
+    per = 1000                                   # even, several segments per 512-ray workgroup tile boundary
+    n = per * len(shells)
+    geo = [(r0, z0, a, w, float(con.primrad(z0, r0, z0)), float(con.primrad(z0 + lmir, r0, z0)))
+           for (r0, z0, a, w) in shells]
+
+    def shell(r, r0, z0, a):
+        tran.transform(r, 0, 0, -(z0 + 2 * lmir), 0, 0, a)
+        surf.wolterprimary(r, r0, z0)
+        tran.reflect(r)
+        surf.woltersecondary(r, r0, z0)
+        tran.reflect(r)
+
+    def fresh():
+        buf = torch.empty((10, n), dtype=torch.float64, device="cuda")
+        return [buf[i] for i in range(10)]
+
+    # per-shell sources vs one segmented source
+    a = fresh()
+    for k, (r0, z0, ang, w, rin, rout) in enumerate(geo):
+        sources.subannulus(rin, rout, w, per, zhat=-1., rng="philox", seed=5, first_index=k * per,
+                           out=[c[k * per:(k + 1) * per] for c in a])
+    b = fresh()
+    sources.segments("subannulus", [(g[4], g[5], g[3], -1.) for g in geo], per, out=b, seed=5)
+    same(a, b)
+    c = [t.clone() for t in a]
+    # (1) loop of plain calls  (2) loop of per-shell fused programs  (3) one segmented launch
+    for k, g in enumerate(geo):
+        shell([t[k * per:(k + 1) * per] for t in a], g[0], g[1], g[2])
+    for k, g in enumerate(geo):
+        with pxf.fused():
+            shell([t[k * per:(k + 1) * per] for t in b], g[0], g[1], g[2])
+    prog = pxf.compile_segments(c, per, shell, [(g[0], g[1], g[2]) for g in geo])
+    assert tuple(prog.table.shape) == (len(shells), 5, 9)
+    prog.run()
+    same(a, b)
+    same(a, c)
+    # a different sequence in one segment is rejected
+    def bad(r, r0, z0, a_):
+        shell(r, r0, z0, a_)
+        if r0 > 330.:
+            surf.flat(r)
+    with pytest.raises(Exception, match="different operation sequence"):
+        pxf.compile_segments(c, per, bad, [(g[0], g[1], g[2]) for g in geo])

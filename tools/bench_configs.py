@@ -230,6 +230,56 @@ def config5(n, reps, lmir=50.):
             gbest = ms if gbest is None else min(gbest, ms)
     res["hip_graph"] = {"ms": gbest, "rays_per_s": n / (gbest * 1e-3), "nodes": 2 * ns + 1}
     res["graph_equals_eager"] = bool(torch.equal(torch.nan_to_num(rays[1]), torch.nan_to_num(ref_x)))
+    del g
+    # the same step as THREE launches: segmented source, segmented two-bounce program (per-shell
+    # parameter blocks staged in LDS), grating program
+    def shell(sl, r0, z0, a_):
+        tran.transform(sl, 0, 0, -(z0 + 2 * lmir), 0, 0, a_)
+        surf.wolterprimary(sl, r0, z0)
+        tran.reflect(sl)
+        surf.woltersecondary(sl, r0, z0)
+        tran.reflect(sl)
+
+    import time as _t
+    t0 = _t.perf_counter()
+    prog = pxf.compile_segments(rays, per, shell, [(g_[0], g_[1], g_[2]) for g_ in geo])
+    res["segmented_compile_s"] = _t.perf_counter() - t0
+    src_par = [(g_[4], g_[5], g_[3], -1.) for g_ in geo]
+
+    def step3(seed):
+        sources.segments("subannulus", src_par, per, out=rays, seed=seed)
+        prog.run()
+        with pxf.fused():
+            tran.transform(rays, 0, ty, 0, rx, 0, 0)
+            surf.flat(rays)
+            tran.reflect(rays)
+            tran.radgrat(rays, 160. / ZG, 1., 2.4)
+            tran.itransform(rays, 0, ty, 0, rx, 0, 0)
+            surf.flat(rays)
+
+    sbest = None
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for r in range(reps + 1):
+        evs[0].record()
+        sources.segments("subannulus", src_par, per, out=rays, seed=51 + reps - 1)
+        evs[1].record()
+        prog.run()
+        evs[2].record()
+        with pxf.fused():
+            tran.transform(rays, 0, ty, 0, rx, 0, 0)
+            surf.flat(rays)
+            tran.reflect(rays)
+            tran.radgrat(rays, 160. / ZG, 1., 2.4)
+            tran.itransform(rays, 0, ty, 0, rx, 0, 0)
+            surf.flat(rays)
+        evs[3].record()
+        torch.cuda.synchronize()
+        ms = evs[0].elapsed_time(evs[3])
+        if r > 0 and (sbest is None or ms < sbest[0]):
+            sbest = (ms, evs[0].elapsed_time(evs[1]), evs[1].elapsed_time(evs[2]), evs[2].elapsed_time(evs[3]))
+    res["segmented"] = {"ms": sbest[0], "rays_per_s": n / (sbest[0] * 1e-3), "launches": 3,
+                        "source_ms": sbest[1], "two_bounce_ms": sbest[2], "grating_ms": sbest[3]}
+    res["segmented_equals_eager"] = bool(torch.equal(torch.nan_to_num(rays[1]), torch.nan_to_num(ref_x)))
     return res
 
 
