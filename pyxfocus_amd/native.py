@@ -45,6 +45,9 @@ def _mask_ptr(mask, num, dev, what):
     return mask.data_ptr()
 
 
+_FN = {}   # name -> bound ctypes function (argtypes already set by _lib.lib())
+
+
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -65,12 +68,18 @@ def _call(name, cols, tail, mask=None, aux_last=False):
         rec.flush()                      # cannot join the pending program: run it, then go on
         if rec.try_add(name, cols, tail, mask):
             return
-    h = _lib.lib()
+    f = _FN.get(name)
+    if f is None:
+        f = _FN[name] = getattr(_lib.lib(), name)
     ptrs = [t.data_ptr() for t in cols]
     extra = [ptrs.pop()] if aux_last else []
-    with torch.cuda.device(dev):
-        rc = getattr(h, name)(*ptrs, num, *tail, *extra, mp, _stream(dev))
-    _lib.check(rc, name)
+    if dev.index == torch.cuda.current_device():          # the common case: skip the device guard (~6 us)
+        rc = f(*ptrs, num, *tail, *extra, mp, _stream(dev))
+    else:
+        with torch.cuda.device(dev):
+            rc = f(*ptrs, num, *tail, *extra, mp, _stream(dev))
+    if rc:
+        _lib.check(rc, name)
 
 
 # ---- surfacesf ------------------------------------------------------------------------------
