@@ -40,6 +40,50 @@ __global__ void probe(Ptrs c, long nvec, double add)
     }
 }
 
+// transform-shaped kernel that touches its nine columns as three sequential groups of three
+// (position, direction, normal are independent): fewer concurrent DRAM streams per workgroup
+template <bool NT>
+__global__ void probe_grouped(Ptrs c, long nvec, double add)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            d2 r[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const d2 *p = reinterpret_cast<const d2 *>(c.p[3 * g + k]) + v;
+                r[k] = NT ? __builtin_nontemporal_load(p) : *p;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                d2 o = r[k] + r[(k + 1) % 3] * add;
+                d2 *p = reinterpret_cast<d2 *>(c.p[3 * g + k]) + v;
+                if (NT) __builtin_nontemporal_store(o, p); else *p = o;
+            }
+        }
+    }
+}
+
+template <bool NT>
+static void run_grouped(Ptrs c, long n, int cus, int reps)
+{
+    const long nvec = n / 2;
+    int grid = (int)((nvec + 255) / 256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL((probe_grouped<NT>), dim3(grid), dim3(256), 0, 0, c, nvec, 1e-9);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((probe_grouped<NT>), dim3(grid), dim3(256), 0, 0, c, nvec, 1e-9);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("grouped3x3 nt%d full grid : %7.3f ms  %7.1f GB/s\n", (int)NT, ms, 18 * 8.0 * n / (ms * 1e-3) / 1e9);
+}
+
 template <int R, int W, int V, bool NTL, bool NTS>
 static void run(const char *name, Ptrs c, long n, int block, int bpc, int cus, int reps)
 {
@@ -78,6 +122,13 @@ int main(int argc, char **argv)
     const int reps = 5;
     int blocks[] = {256, 512, 1024};
     int bpcs[] = {4, 8, 16, 32, 0};
+    for (int rep = 0; rep < 3; rep++) {   // interleaved: plain 9+9 vs grouped 3x(3+3), full grid
+        run<9, 9, 2, false, false>("transform", c, n, 256, 0, cus, reps);
+        run_grouped<false>(c, n, cus, reps);
+        run<9, 9, 2, true, true>("transform", c, n, 256, 0, cus, reps);
+        run_grouped<true>(c, n, cus, reps);
+    }
+    return 0;
     // transform shape
     for (int b : blocks)
         for (int bpc : bpcs) {
