@@ -21,7 +21,8 @@ _ws_cache = {}
 
 
 def _workspace(dev):
-    key = (dev.type, dev.index)
+    # one scratch buffer per (device, stream): reductions issued on different streams may overlap
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     if key not in _ws_cache:
         nbytes = _lib.lib().pxf_reduce_workspace_bytes()
         _ws_cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
