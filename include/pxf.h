@@ -309,6 +309,9 @@ int pxf_central_moments(const double *x, const double *y, const double *w, int64
 /* analyses.rho (analyses.py:60-71): out[i] = sqrt((x-cx)^2 + (y-cy)^2) */
 int pxf_rho(const double *x, const double *y, double cx, double cy, double *out, int64_t num,
             pxf_stream_t stream);
+/* analyses.measureOPD (analyses.py:231-244): out[i] = |(x,y,z)_i - (px,py,pz)| */
+int pxf_dist3(const double *x, const double *y, const double *z, double px, double py, double pz, double *out,
+              int64_t num, pxf_stream_t stream);
 /* analyses.indAngle / grazeAngle (analyses.py:164-187): out[i] = acos(d.u)  (graze!=0: pi/2 - acos(d.u)) */
 int pxf_indangle(const double *l, const double *m, const double *n, const double *ux, const double *uy,
                  const double *uz, double *out, int64_t num, int32_t graze, pxf_stream_t stream);

@@ -78,6 +78,7 @@ _SIGS = {
     "pxf_moments": [_P] * 6 + [_i64, _P, _P, _P],
     "pxf_central_moments": [_P] * 3 + [_i64, _d, _d, _P, _P, _P],
     "pxf_rho": [_P, _P, _d, _d, _P, _i64, _P],
+    "pxf_dist3": [_P, _P, _P, _d, _d, _d, _P, _i64, _P],
     "pxf_indangle": [_P] * 7 + [_i64, _i32, _P],
     "pxf_select_workspace_bytes": [],
     "pxf_kth_values": [_P, _i64, C.POINTER(C.c_int64), _i32, _P, _P, _P],

@@ -90,6 +90,30 @@ def rmsCentroid(rays, weights=None, group=None):
     return math.sqrt(s[1] / s[0])
 
 
+def measureOPD(rays, point):
+    """Distance in mm from every ray to `point` -- a 3-vector, or a 10-element single-ray list whose
+    entries 1..3 are used (analyses.py:231-244).  Returns a device tensor."""
+    fused.flush()
+    x, y, z = rays[1:4]
+    num, dev = native._check_cols((x, y, z), "measureOPD")
+    p = [float(v) for v in (point[1:4] if len(point) == 10 else point[:3])]
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_dist3(x.data_ptr(), y.data_ptr(), z.data_ptr(), *p, out.data_ptr(), num,
+                                  native._stream(dev))
+    _lib.check(rc, "pxf_dist3")
+    return out
+
+
+def rmsPoint(rays, point, weights=None):
+    """RMS of the rays about a point (analyses.py:32-44)."""
+    d = measureOPD(rays, point)
+    if weights is None:
+        return math.sqrt(float((d * d).mean()))
+    w = _weights(weights, d.shape[0], d.device)
+    return math.sqrt(float((w * d * d).sum() / w.sum()))
+
+
 def rmsX(rays, weights=None, group=None):
     """RMS from centroid in the X direction (analyses.py:46-51)."""
     cx, cy = centroid(rays, weights=weights, group=group)

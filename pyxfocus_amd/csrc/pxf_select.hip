@@ -138,6 +138,24 @@ struct RhoOp {
     }
 };
 
+// analyses.measureOPD (analyses.py:231-244): distance of every ray from a point
+struct Dist3Op {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = POS;
+    static constexpr unsigned WR = B(AUX);
+    double px, py, pz;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const double dx = r[k].c[X] - px, dy = r[k].c[Y] - py, dz = r[k].c[Z] - pz;
+            r[k].c[AUX] = sqrt(dx * dx + dy * dy + dz * dz);
+            wm[k] = WR;
+        }
+    }
+};
+
 struct IndAngleOp {
     PXF_OP_DEFAULTS
     static constexpr unsigned RD = DIR | NRM;
@@ -180,6 +198,17 @@ int pxf_indangle(const double *l, const double *m, const double *n, const double
     for (int i = 0; i < 6; i++) c.p[L + i] = const_cast<double *>(src[i]);
     c.p[AUX] = out;
     return launch_rays(c, num, nullptr, stream, IndAngleOp{graze});
+}
+
+int pxf_dist3(const double *x, const double *y, const double *z, double px, double py, double pz, double *out,
+              int64_t num, pxf_stream_t stream)
+{
+    Cols c{};
+    c.p[X] = const_cast<double *>(x);
+    c.p[Y] = const_cast<double *>(y);
+    c.p[Z] = const_cast<double *>(z);
+    c.p[AUX] = out;
+    return launch_rays(c, num, nullptr, stream, Dist3Op{px, py, pz});
 }
 
 size_t pxf_select_workspace_bytes(void) { return sizeof(SelState); }

@@ -587,3 +587,19 @@ def test_lenses_and_oap_vs_oracle_composition(port):
     T.reflect(*a[3:])
     for k, r in zip(ALLCOLS[1:], host(ps)[1:]):          # ps itself was traced in place (local frame)
         assert bits_equal(r, w[k]).all(), k
+
+
+def test_measure_opd_and_rms_point():
+    import pyxfocus_amd.analyses as anal
+    from oracle import cases
+    rng = np.random.default_rng(6)
+    c = cases._randrays(rng, 50_001)
+    rays = [torch.from_numpy(c[k]).cuda() for k in ALLCOLS]
+    pt = (1.5, -2.5, 30.)
+    d = np.sqrt((c["x"] - pt[0]) ** 2 + (c["y"] - pt[1]) ** 2 + (c["z"] - pt[2]) ** 2)
+    assert np.array_equal(anal.measureOPD(rays, pt).cpu().numpy(), d)
+    ten = [0., 1.5, -2.5, 30., 0, 0, 0, 0, 0, 0]
+    assert np.array_equal(anal.measureOPD(rays, ten).cpu().numpy(), d)
+    assert abs(anal.rmsPoint(rays, pt) - np.sqrt(np.average(d ** 2))) < 1e-11
+    w = rng.random(50_001)
+    assert abs(anal.rmsPoint(rays, pt, weights=w) - np.sqrt(np.average(d ** 2, weights=w))) < 1e-11
