@@ -196,6 +196,15 @@ int pxf_tracezernopd(double *opd, double *x, double *y, double *z, const double 
                      const double *coeff, const int32_t *rorder, const int32_t *aorder,
                      int32_t arrsize, double rad, double nr, const uint8_t *mask, pxf_stream_t stream);
 
+/* EXTENSION (no reference counterpart; BASELINE config 4's "Zernike-perturbed conic"): Newton trace to
+ *   z = c rho^2 / (1 + sqrt(1 - (K+1) c^2 rho^2)) + sum_i coeff_i Z_i(rho/rad, theta),  c = 1/R,
+ * vertex at the origin opening toward +z like `conic`; Zernike orders up to n = 10.  opd may be NULL
+ * (then nr is ignored).  Parity unpinned: validated against pxf_conic (coeff = 0) and an independent
+ * NumPy Newton (tests/test_gpu_wrappers.py). */
+int pxf_tracezernconic(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+                       const double *n, double *ux, double *uy, double *uz, int64_t num, double R, double K,
+                       const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
+                       double rad, double nr, const uint8_t *mask, pxf_stream_t stream);
 /* tracezernrot(x,...,uz,num,coeff1,rorder1,aorder1,arrsize1,coeff2,rorder2,aorder2,arrsize2,rad,rot)
  * zernsurf.f95:257-359: sum of two Zernike sets, the second evaluated at theta+rot (folded into one
  * table on the host by the angle-addition identities). */

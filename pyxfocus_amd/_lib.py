@@ -49,6 +49,7 @@ _SIGS = {
     "pxf_conicplus": [_P] * 9 + [_i64, _d, _d, _DP, _i32, _P, _P],
     "pxf_conicplusopd": [_P] * 10 + [_i64, _d, _d, _DP, _i32, _d, _P, _P],
     "pxf_legsurf": [_P] * 5 + [_i64, _d, _d, _d, _DP, _IP, _IP, _i32, _P, _P],
+    "pxf_tracezernconic": [_P] * 10 + [_i64, _d, _d, _DP, _IP, _IP, _i32, _d, _d, _P, _P],
     "pxf_tracezernrot": [_P] * 9 + [_i64, _DP, _IP, _IP, _i32, _DP, _IP, _IP, _i32, _d, _d, _P, _P],
     "pxf_zernphase": [_P] * 6 + [_i64, _DP, _IP, _IP, _i32, _d, _d, _P, _P],
     "pxf_spocone": [_P] * 9 + [_i64, _d, _d, _P, _P],

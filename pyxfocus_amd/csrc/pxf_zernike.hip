@@ -104,7 +104,11 @@ __device__ __forceinline__ void zern_eval(const double2 *__restrict__ tab, doubl
     Sy = st * Srho + ct * Sth;
 }
 
-template <int NMAX>
+// CONIC: EXTENSION without a reference counterpart (BASELINE config 4 names a "Zernike-perturbed
+// conic"; the reference's zernsurf is a pure Zernike sag): the sag of a conic of radius
+// R and constant K is added under the Zernike sum,  F = z - c rho^2/(1+sqrt(1-(K+1) c^2 rho^2)) - S.
+// Parity unpinned; checked against the conic kernel (coeff = 0) and an independent NumPy Newton.
+template <int NMAX, bool CONIC = false>
 struct ZernOp {
     static constexpr int MAXV = 1;
     static constexpr unsigned RD = POS | DIR | B(OPD);  // opd column only touched when has_opd
@@ -113,6 +117,7 @@ struct ZernOp {
     double2 tab_arg[zern_npairs(NMAX)];  // folded table, by value in the kernel-argument segment
     double rad, nr;
     int has_opd;
+    double cc = 0., K1 = 0.;  // conic: curvature 1/R and K+1 (CONIC only)
 
     __device__ __forceinline__ double2 *lds() const
     {
@@ -141,10 +146,18 @@ struct ZernOp {
         for (int it = 0; act && it < kNewtonCap; it++) {
             double S, Sx, Sy;
             zern_eval<NMAX>(tab, x, y, rad, inv_rad, S, Sx, Sy);
-            const double F = z - S;   // F = z - sum c_i Z_i ; grad F = (-dS/dx, -dS/dy, 1)
+            double F = z - S;   // F = z - sum c_i Z_i ; grad F = (-dS/dx, -dS/dy, 1)
             Fx = -Sx;
             Fy = -Sy;
             Fz = 1.;
+            if (CONIC) {
+                const double r2 = x * x + y * y;
+                const double sq = sqrt(1. - K1 * cc * cc * r2);
+                F -= cc * r2 / (1. + sq);
+                const double g = cc / sq;  // (1/rho) d(sag)/d(rho)
+                Fx -= g * x;
+                Fy -= g * y;
+            }
             const double Fp = Fx * l + Fy * m + Fz * n;
             const double delta = -F / Fp;
             x = x + l * delta;
@@ -168,15 +181,15 @@ struct ZernOp {
 // The opd column is optional: the generic kernel loads every RD column, so the plain variant
 // points OPD at x (a harmless extra 8 B/ray read would be wasteful -- instead use a distinct Op
 // without OPD).  Two thin wrappers select the column sets at compile time.
-template <int NMAX, bool WOPD>
-struct ZernOpSel : ZernOp<NMAX> {
+template <int NMAX, bool WOPD, bool CONIC = false>
+struct ZernOpSel : ZernOp<NMAX, CONIC> {
     static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
     static constexpr unsigned WR = POS | NRM | (WOPD ? B(OPD) : 0u);
     template <int V>
     __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
     {
         if (!WOPD) r[0].c[OPD] = 0.;
-        ZernOp<NMAX>::template apply<V>(r, sel, wm);
+        ZernOp<NMAX, CONIC>::template apply<V>(r, sel, wm);
     }
 };
 
@@ -256,11 +269,13 @@ static int fold_table(const double *coeff, const int32_t *rorder, const int32_t 
     return PXF_OK;
 }
 
-template <int NMAX, bool WOPD>
+template <int NMAX, bool WOPD, bool CONIC = false>
 static int launch_nmax(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream,
-                       const ZernTab &tab, double rad, double nr)
+                       const ZernTab &tab, double rad, double nr, double cc = 0., double K1 = 0.)
 {
-    ZernOpSel<NMAX, WOPD> op;
+    ZernOpSel<NMAX, WOPD, CONIC> op;
+    op.cc = cc;
+    op.K1 = K1;
     for (int i = 0; i < zern_npairs(NMAX); i++) op.tab_arg[i] = tab.a[i];
     op.rad = rad;
     op.nr = nr;
@@ -277,6 +292,19 @@ static int dispatch_nmax(int nmax, const Cols &c, int64_t num, const uint8_t *ma
     } else {
         if (nmax >= NMAX) return launch_nmax<NMAX, WOPD>(c, num, mask, stream, tab, rad, nr);
         return dispatch_nmax<WOPD, NMAX - 1>(nmax, c, num, mask, stream, tab, rad, nr);
+    }
+}
+
+// the conic extension is instantiated for the even orders up to 10 only (compile time)
+template <bool WOPD, int NMAX = 10>
+static int dispatch_conic(int nmax, const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream,
+                          const ZernTab &tab, double rad, double nr, double cc, double K1)
+{
+    if constexpr (NMAX < 2) {
+        return launch_nmax<2, WOPD, true>(c, num, mask, stream, tab, rad, nr, cc, K1);
+    } else {
+        if (nmax > NMAX - 2) return launch_nmax<NMAX, WOPD, true>(c, num, mask, stream, tab, rad, nr, cc, K1);
+        return dispatch_conic<WOPD, NMAX - 2>(nmax, c, num, mask, stream, tab, rad, nr, cc, K1);
     }
 }
 
@@ -361,6 +389,33 @@ int pxf_tracezernopd(double *opd, double *x, double *y, double *z, const double 
 {
     return run<true>(opd, x, y, z, l, m, n, ux, uy, uz, num, coeff, rorder, aorder, arrsize, rad, nr, mask,
                      stream);
+}
+
+int pxf_tracezernconic(double *opd, double *x, double *y, double *z, const double *l, const double *m,
+                       const double *n, double *ux, double *uy, double *uz, int64_t num, double R, double K,
+                       const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
+                       double rad, double nr, const uint8_t *mask, pxf_stream_t stream)
+{
+    ZernTab tab;
+    int nmax = 0;
+    int rc = fold_table(coeff, rorder, aorder, arrsize, tab, nmax);
+    if (rc != PXF_OK) return rc;
+    if (nmax > 10) return PXF_ERANGE;
+    if (num < 0 || R == 0.) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
+    Cols c{};
+    c.p[OPD] = opd;
+    c.p[X] = x;
+    c.p[Y] = y;
+    c.p[Z] = z;
+    c.p[L] = const_cast<double *>(l);
+    c.p[M] = const_cast<double *>(m);
+    c.p[N] = const_cast<double *>(n);
+    c.p[UX] = ux;
+    c.p[UY] = uy;
+    c.p[UZ] = uz;
+    if (opd) return dispatch_conic<true>(nmax, c, num, mask, stream, tab, rad, nr, 1. / R, K + 1.);
+    return dispatch_conic<false>(nmax, c, num, mask, stream, tab, rad, 0., 1. / R, K + 1.);
 }
 
 int pxf_tracezernrot(double *x, double *y, double *z, const double *l, const double *m, const double *n,

@@ -273,6 +273,20 @@ def tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, 
           (cp, rp, ap, len(ck), float(rad), float(nr)), mask)
 
 
+def tracezernconic(opd, x, y, z, l, m, n, ux, uy, uz, R, K, coeff, rorder, aorder, rad, nr=0., mask=None):
+    """EXTENSION (no f2py counterpart): conic of radius R, constant K plus a Zernike sag.  opd may be None."""
+    cols = (x, y, z, l, m, n, ux, uy, uz)
+    num, dev = _check_cols(cols if opd is None else (opd,) + cols, "pxf_tracezernconic")
+    ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    mp = _mask_ptr(mask, num, dev, "pxf_tracezernconic")
+    fused.flush()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_tracezernconic(None if opd is None else opd.data_ptr(), *[t.data_ptr() for t in cols],
+                                           num, float(R), float(K), cp, rp, ap, len(ck), float(rad), float(nr),
+                                           mp, _stream(dev))
+    _lib.check(rc, "pxf_tracezernconic")
+
+
 def zernphase(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, wave, mask=None):
     _check_cols((opd, x, y, z, l, m, n, ux, uy, uz), "pxf_zernphase")
     ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
@@ -352,6 +366,6 @@ woltsurf = SimpleNamespace(wolterprimary=wolterprimary, wolterprimaryopd=wolterp
                            wsprimary=wsprimary, wssecondary=wssecondary, wsprimaryback=wsprimaryback,
                            wssecondaryback=wssecondaryback)
 zernsurf = SimpleNamespace(tracezern=tracezern, tracezernopd=tracezernopd, zernphase=zernphase,
-                           tracezernrot=tracezernrot)
+                           tracezernrot=tracezernrot, tracezernconic=tracezernconic)
 transformationsf = SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
                                    radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract)

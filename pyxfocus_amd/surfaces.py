@@ -19,7 +19,7 @@ __all__ = ["flat", "zernsurf", "conic", "wolterprimary", "wolterprimarynode", "w
            "paraxialY", "spoCone", "spoPrimary", "spoSecondary", "woltersine", "primaryLL", "secondaryLL",
            "wsPrimary", "wsSecondary", "ellipsoidPrimary", "ellipsoidSecondary", "ellipsoidPrimaryLL",
            "ellipsoidSecondaryLL", "zernphase", "zernsurfrot", "conicplus", "torus", "legSurf", "wsPrimaryB",
-           "wsSecondaryB", "oapCollimate"]
+           "wsSecondaryB", "oapCollimate", "zernconic"]
 
 
 def flat(rays, ind=None, nr=None):
@@ -65,6 +65,18 @@ def zernsurf(rays, coeff, rad, rorder=None, aorder=None, nr=None):
         zern.tracezern(x, y, z, l, m, n, ux, uy, uz, coeff, np.array(rorder), np.array(aorder), rad)
     else:
         zern.tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, np.array(rorder), np.array(aorder), rad, nr)
+    return
+
+
+def zernconic(rays, R, K, coeff, rad, rorder=None, aorder=None, nr=None):
+    """EXTENSION -- not in PyXFocus: a conic (radius of curvature R, conic constant K, vertex at the
+    origin, as `conic`) perturbed by a Zernike sag (as `zernsurf`): BASELINE config 4's
+    "Zernike-perturbed conic".  Newton trace, tolerance 1e-10 mm, normal as in `zernsurf`."""
+    opd, x, y, z, l, m, n, ux, uy, uz = rays
+    if rorder is None:
+        rorder, aorder = zmodes(np.size(coeff))
+    zern.tracezernconic(opd if nr is not None else None, x, y, z, l, m, n, ux, uy, uz, R, K, coeff,
+                        np.array(rorder), np.array(aorder), rad, nr=0. if nr is None else nr)
     return
 
 

