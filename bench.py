@@ -132,7 +132,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PXF_BENCH_FORCE_DIST"):     # (the env knob rehearses the RCCL path on 1 GPU)
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)

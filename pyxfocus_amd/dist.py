@@ -30,8 +30,6 @@ def all_gather_focal(cols, group=None):
     """cols: list of equal-length 1-D tensors (this rank's surviving rays).  Returns a list of the
     same columns concatenated over ranks in rank order (i.e. global ray order)."""
     world = dist.get_world_size(group)
-    if world == 1:
-        return [c.clone() for c in cols]
     n = cols[0].shape[0]
     dev, dt = cols[0].device, cols[0].dtype
     cnt = torch.tensor([n], dtype=torch.int64, device=dev)
