@@ -51,17 +51,6 @@ constexpr int kNewtonCap = 1000;  // the reference has none (it would hang); nev
 #define PXF_TOL_1EM8 ((double)1.e-8f)
 #define PXF_TOL_1EM10 ((double)1.e-10f)
 
-template <int V>
-struct VecT;
-template <>
-struct VecT<1> {
-    using type = double;
-};
-template <>
-struct VecT<2> {
-    using type = double2;
-};
-
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // NT = non-temporal access.  Measured on MI355X (tools/ab_kernels.py, interleaved rounds): for a

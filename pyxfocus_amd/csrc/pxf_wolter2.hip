@@ -70,7 +70,7 @@ struct LLOp {
     double twop, pp, cst;    // primary
     double e2, twoe2, d;     // secondary
     double aa2, bb2, zfoc;   // ellipsoid: aa**2, bb**2
-    double tol, zmid, zhalf, two_over_dphi, two_over_dz;  // (zmax+zmin)/2, (zmax-zmin)/2, 2/dphi, 2/(zmax-zmin) pieces
+    double tol, zmid, zhalf;  // Newton tolerance, (zmax+zmin)/2, (zmax-zmin)/2
     double dphi, zspan;      // dphi, zmax-zmin
     int ka, kt;              // highest axial / azimuthal order present
     double cmat[kLLMax];     // C[i*(kt+1)+j], by value in the kernel-argument segment
@@ -494,8 +494,6 @@ static int fold_ll(LLOp<KIND> &op, double zmax, double zmin, double dphi, const 
     op.zhalf = (zmax - zmin) / 2.;
     op.dphi = dphi;
     op.zspan = zmax - zmin;
-    op.two_over_dphi = 0.;
-    op.two_over_dz = 0.;
     return PXF_OK;
 }
 
