@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no binaries (they are git-ignored): build the HIP library (hipcc
+    cross-compiles without a GPU) and the oracle once, exactly as __graft_entry__.build() does."""
+    need = [os.path.join(ROOT, "pyxfocus_amd", "csrc", "libpxf_hip.so"),
+            os.path.join(ROOT, "oracle", "libpxf_oracle.so"), os.path.join(ROOT, "oracle", "libpxf_oracle_omp.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def port():
     """The C restatement (oracle/pxf_oracle.c) -- the checker."""
