@@ -344,8 +344,22 @@ int pxf_kth_values(const double *v, int64_t num, const int64_t *k, int32_t nk, d
 #define PXF_SRC_ANNULUS 2      /* p0 = rin, p1 = rout, p3 = zhat   sources.py:91-127  */
 #define PXF_SRC_SUBANNULUS 3   /* p0 = rin, p1 = rout, p2 = dphi, p3 = zhat  sources.py:130-170 */
 #define PXF_SRC_RECTBEAM 4     /* p0 = xhalfwidth, p1 = yhalfwidth sources.py:348-377 */
+/* the remaining sources.py generators; parameters in a HOST double[7] (pxf_source_ex) */
+#define PXF_SRC_XSLIT 5            /* xin, xout, -, zhat                       sources.py:173-207  (grid) */
+#define PXF_SRC_RECTARRAY 6        /* xsize, ysize, n per side                 sources.py:210-247  (grid) */
+#define PXF_SRC_CONVERGINGBEAM 7   /* zset, rin, rout, tmin, tmax, lscat       sources.py:250-297  */
+#define PXF_SRC_CONVERGINGBEAM2 8  /* zset, xmin, xmax, ymin, ymax, lscat      sources.py:300-345  */
+#define PXF_SRC_GAUSSIANBEAM 9     /* ang                                      sources.py:380-413  */
+#define PXF_SRC_FANBEAM 10         /* xang, yang, n per side                   sources.py:416-438  (grid) */
+#define PXF_SRC_CIRCFAN 11         /* halfang, rings, arms                     sources.py:441-471  (grid) */
 int pxf_source(int32_t kind, double *const *cols, int64_t num, double p0, double p1, double p2,
                double p3, uint64_t seed, uint64_t first_index, pxf_stream_t stream);
+
+/* Extended kinds 5..11.  `num` rays are generated for global indices first_index .. first_index+num-1
+ * of a bundle of `total` rays (the grid kinds need the full length: np.linspace(.., total)); the grid
+ * kinds reproduce NumPy's linspace/meshgrid positions bit for bit (direction cosines to an ulp of sin/cos), the random ones are distribution-equal. */
+int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total, const double *params,
+                  uint64_t seed, uint64_t first_index, pxf_stream_t stream);
 
 /* ---- fused ray program ---------------------------------------------------------------------------
  * The reference makes one pass over the bundle per API call (576 B/ray of HBM traffic for the

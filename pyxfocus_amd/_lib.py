@@ -13,7 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PXF_LIB") or os.path.join(_HERE, "csrc", "libpxf_hip.so")
 
 PXF_NMOM = 12
-SRC_KINDS = {"pointsource": 0, "circularbeam": 1, "annulus": 2, "subannulus": 3, "rectbeam": 4}
+SRC_KINDS = {"pointsource": 0, "circularbeam": 1, "annulus": 2, "subannulus": 3, "rectbeam": 4, "xslit": 5,
+             "rectArray": 6, "convergingbeam": 7, "convergingbeam2": 8, "gaussianBeam": 9, "fanBeam": 10,
+             "circFan": 11}
 
 _P = C.c_void_p          # device pointer (tensor.data_ptr()) or NULL
 _d, _i64, _i32, _u64 = C.c_double, C.c_int64, C.c_int32, C.c_uint64
@@ -84,6 +86,7 @@ _SIGS = {
     "pxf_select_workspace_bytes": [],
     "pxf_kth_values": [_P, _i64, C.POINTER(C.c_int64), _i32, _P, _P, _P],
     "pxf_source": [_i32, _PP, _i64, _d, _d, _d, _d, _u64, _u64, _P],
+    "pxf_source_ex": [_i32, _PP, _i64, _i64, _DP, _u64, _u64, _P],
     "pxf_program_run": [_P, _i32, _PP, _i64, _P],
     "pxf_program_params": [_P, _i32, _DP, C.POINTER(C.c_int32)],
     "pxf_program_run_segments": [_P, _i32, _P, _i32, _i64, _PP, _i64, _P],

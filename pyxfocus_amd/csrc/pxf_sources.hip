@@ -32,10 +32,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
-// two 53-bit uniforms in [0,1) per global ray index (same construction as NumPy's random_sample)
-__device__ __forceinline__ void uniform2(uint64_t seed, uint64_t index, double &u1, double &u2)
+// two 53-bit uniforms in [0,1) per global ray index (same construction as NumPy's random_sample);
+// `draw` selects further independent pairs for the same ray (third counter word)
+__device__ __forceinline__ void uniform2(uint64_t seed, uint64_t index, double &u1, double &u2, uint32_t draw = 0u)
 {
-    uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), 0u, 0u};
+    uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), draw, 0u};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     const uint64_t a = ((uint64_t)c[0] << 32) | c[1], b = ((uint64_t)c[2] << 32) | c[3];
     u1 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
@@ -45,7 +46,18 @@ __device__ __forceinline__ void uniform2(uint64_t seed, uint64_t index, double &
 struct SrcParams {
     double p0, p1, p2, p3;
     uint64_t seed, first;
+    double p4 = 0., p5 = 0., p6 = 0.;  // extended kinds only
+    int64_t total = 0;                  // bundle length (grids need it: linspace(.., num))
 };
+
+// np.linspace(start, stop, n)[i]: i*step + start with step = (stop-start)/(n-1), last element = stop
+__device__ __forceinline__ double linspace_at(double start, double stop, int64_t n, int64_t i)
+{
+    if (n <= 1) return start;
+    if (i == n - 1) return stop;
+    const double step = (stop - start) / (double)(n - 1);
+    return (double)i * step + start;
+}
 
 template <int KIND>
 __device__ __forceinline__ void make_ray(const SrcParams &q, uint64_t gidx, double (&c)[10])
@@ -79,10 +91,66 @@ __device__ __forceinline__ void make_ray(const SrcParams &q, uint64_t gidx, doub
         c[X] = rho * cos(th);
         c[Y] = rho * sin(th);
         c[N] = q.p3;
-    } else {  // PXF_SRC_RECTBEAM, sources.py:364-367
+    } else if (KIND == PXF_SRC_RECTBEAM) {  // sources.py:364-367
         c[X] = (u1 - .5) * 2 * q.p0;
         c[Y] = (u2 - .5) * 2 * q.p1;
         c[N] = 1.;
+    } else if (KIND == PXF_SRC_XSLIT) {  // sources.py:195-204 (deterministic)
+        c[X] = linspace_at(q.p0, q.p1, q.total, (int64_t)gidx);
+        c[N] = q.p3;
+    } else if (KIND == PXF_SRC_RECTARRAY) {  // sources.py:230-245: meshgrid(linspace x, linspace y).flatten()
+        const int64_t nside = (int64_t)q.p2;
+        const int64_t ix = (int64_t)gidx % nside, iy = (int64_t)gidx / nside;
+        c[X] = linspace_at(-q.p0, q.p0, nside, ix);
+        c[Y] = linspace_at(-q.p1, q.p1, nside, iy);
+        c[N] = 1.;
+    } else if (KIND == PXF_SRC_CONVERGINGBEAM || KIND == PXF_SRC_CONVERGINGBEAM2) {
+        // sources.py:279-295 / 327-343: p0 zset; beam: p1 rin, p2 rout, p3 tmin, p4 tmax | beam2: p1 xmin,
+        // p2 xmax, p3 ymin, p4 ymax; p5 lscat [arcsec], Lorentzian angular scatter
+        double u3, u4;
+        uniform2(q.seed, gidx, u3, u4, 1u);
+        double x, y, rho, th;
+        if (KIND == PXF_SRC_CONVERGINGBEAM) {
+            rho = sqrt(q.p1 * q.p1 + u1 * (q.p2 * q.p2 - q.p1 * q.p1));
+            th = q.p3 + u2 * (q.p4 - q.p3);
+            x = rho * cos(th);
+            y = rho * sin(th);
+        } else {
+            x = q.p1 + u1 * (q.p2 - q.p1);
+            y = q.p3 + u2 * (q.p4 - q.p3);
+            rho = sqrt(x * x + y * y);
+            th = atan2(y, x);
+        }
+        double ls = q.p5 * tan((u3 - .5) * 3.141592653589793);
+        ls = ls / (60. * 60.) * 3.141592653589793 / 180.;
+        const double nn = -cos(atan(rho / q.p0) + ls);
+        const double s = sqrt(1 - nn * nn);
+        c[X] = x;
+        c[Y] = y;
+        c[Z] = q.p0;
+        c[L] = -s * cos(th);
+        c[M] = -s * sin(th);
+        c[N] = nn;
+    } else if (KIND == PXF_SRC_GAUSSIANBEAM) {  // sources.py:404-406, two normals by Box-Muller
+        const double rr = sqrt(-2. * log(1. - u1));  // 1-u1 in (0,1]
+        const double sg = sin(q.p0) / sqrt(2.);
+        c[L] = rr * cos(twopi * u2) * sg;
+        c[M] = rr * sin(twopi * u2) * sg;
+        c[N] = sqrt(1. - c[L] * c[L] - c[M] * c[M]);
+    } else if (KIND == PXF_SRC_FANBEAM) {  // sources.py:420-431: p0 xang, p1 yang, p2 n per side
+        const int64_t nside = (int64_t)q.p2;
+        const int64_t ix = (int64_t)gidx % nside, iy = (int64_t)gidx / nside;
+        c[L] = sin(linspace_at(-q.p0, q.p0, nside, ix));
+        c[M] = sin(linspace_at(-q.p1, q.p1, nside, iy));
+        c[N] = sqrt(1. - c[L] * c[L] - c[M] * c[M]);
+    } else {  // PXF_SRC_CIRCFAN, sources.py:445-461: p0 halfang, p1 rings, p2 arms; index = arm*rings + ring
+        const int64_t rings = (int64_t)q.p1, arms = (int64_t)q.p2;
+        const int64_t ir = (int64_t)gidx % rings, ia = (int64_t)gidx / rings;
+        const double rad = linspace_at(0., q.p0, rings, ir);
+        const double az = linspace_at(0., twopi, arms + 1, ia);
+        c[L] = sin(sin(rad) * cos(az));
+        c[M] = sin(sin(rad) * sin(az));
+        c[N] = sqrt(1. - c[L] * c[L] - c[M] * c[M]);
     }
 }
 
@@ -196,6 +264,34 @@ extern "C" int pxf_source(int32_t kind, double *const *cols, int64_t num, double
         case PXF_SRC_ANNULUS: launch_kind<PXF_SRC_ANNULUS>(c, aligned, num, q, s); break;
         case PXF_SRC_SUBANNULUS: launch_kind<PXF_SRC_SUBANNULUS>(c, aligned, num, q, s); break;
         case PXF_SRC_RECTBEAM: launch_kind<PXF_SRC_RECTBEAM>(c, aligned, num, q, s); break;
+        default: return PXF_EINVAL;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+extern "C" int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total, const double *params,
+                             uint64_t seed, uint64_t first_index, pxf_stream_t stream)
+{
+    if (num < 0 || !cols || !params || total < num) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
+    Cols c{};
+    bool aligned = true;
+    for (int k = 0; k < 10; k++) {
+        if (!cols[k]) return PXF_EINVAL;
+        c.p[k] = cols[k];
+        if ((uintptr_t)cols[k] & 15) aligned = false;
+    }
+    SrcParams q{params[0], params[1], params[2], params[3], seed, first_index, params[4], params[5], params[6], total};
+    hipStream_t s = (hipStream_t)stream;
+    switch (kind) {
+        case PXF_SRC_XSLIT: launch_kind<PXF_SRC_XSLIT>(c, aligned, num, q, s); break;
+        case PXF_SRC_RECTARRAY: launch_kind<PXF_SRC_RECTARRAY>(c, aligned, num, q, s); break;
+        case PXF_SRC_CONVERGINGBEAM: launch_kind<PXF_SRC_CONVERGINGBEAM>(c, aligned, num, q, s); break;
+        case PXF_SRC_CONVERGINGBEAM2: launch_kind<PXF_SRC_CONVERGINGBEAM2>(c, aligned, num, q, s); break;
+        case PXF_SRC_GAUSSIANBEAM: launch_kind<PXF_SRC_GAUSSIANBEAM>(c, aligned, num, q, s); break;
+        case PXF_SRC_FANBEAM: launch_kind<PXF_SRC_FANBEAM>(c, aligned, num, q, s); break;
+        case PXF_SRC_CIRCFAN: launch_kind<PXF_SRC_CIRCFAN>(c, aligned, num, q, s); break;
         default: return PXF_EINVAL;
     }
     hipError_t e = hipGetLastError();

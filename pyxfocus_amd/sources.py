@@ -40,7 +40,7 @@ def _pack(cols, device):
     return [torch.from_numpy(np.array(c, dtype=np.float64, order="C", copy=True)).to(dev) for c in cols]
 
 
-def _philox(kind, num, p, seed, first_index, device, out=None):
+def _philox(kind, num, p, seed, first_index, device, out=None, total=None):
     num = int(num)
     if out is not None:
         # generate INTO an existing bundle (e.g. one shell's slice of a multi-shell bundle)
@@ -59,11 +59,18 @@ def _philox(kind, num, p, seed, first_index, device, out=None):
             buf = torch.empty((10, num), dtype=torch.float64, device=dev)   # one allocation, ten SoA columns
             rays = [buf[i] for i in range(10)]
     arr = (C.c_void_p * 10)(*[r.data_ptr() for r in rays])
+    st = torch.cuda.current_stream(dev).cuda_stream
+    if _lib.SRC_KINDS[kind] >= 5:       # extended kinds: parameters as a host array, bundle length `total`
+        par = (C.c_double * 7)(*([float(v) for v in p] + [0.] * (7 - len(p))))
+        with torch.cuda.device(dev):
+            rc = _lib.lib().pxf_source_ex(_lib.SRC_KINDS[kind], arr, num, int(total if total is not None else num),
+                                          par, int(seed) & (2 ** 64 - 1), int(first_index), st)
+        _lib.check(rc, "pxf_source_ex")
+        return rays
     p = list(p) + [0.] * (4 - len(p))
     with torch.cuda.device(dev):
         rc = _lib.lib().pxf_source(_lib.SRC_KINDS[kind], arr, num, *[float(v) for v in p],
-                                   int(seed) & (2 ** 64 - 1), int(first_index),
-                                   torch.cuda.current_stream(dev).cuda_stream)
+                                   int(seed) & (2 ** 64 - 1), int(first_index), st)
     _lib.check(rc, "pxf_source")
     return rays
 
@@ -135,24 +142,31 @@ def subannulus(rin, rout, dphi, num, zhat=1., device=None, rng="numpy", seed=0, 
                   zero, zero, zero], device)
 
 
-def xslit(xin, xout, num, zhat=-1., device=None):
-    """Slit of rays along x (sources.py:173-207)."""
+def xslit(xin, xout, num, zhat=-1., device=None, on_device=False):
+    """Slit of rays along x (sources.py:173-207).  on_device=True builds the grid on the GPU
+    (same values: np.linspace is reproduced bit for bit)."""
+    if on_device:
+        return _philox("xslit", num, (xin, xout, 0., zhat), 0, 0, device)
     zero = np.repeat(0., num)
     return _pack([zero, np.linspace(xin, xout, num), zero, zero, zero, zero, np.repeat(zhat, num),
                   zero, zero, zero], device)
 
 
-def rectArray(xsize, ysize, num, device=None):
+def rectArray(xsize, ysize, num, device=None, on_device=False):
     """Regular num x num grid over [-xsize,xsize] x [-ysize,ysize]; rays point +z (sources.py:210-247)."""
+    if on_device:
+        return _philox("rectArray", num ** 2, (xsize, ysize, num), 0, 0, device)
     x, y = np.meshgrid(np.linspace(-xsize, xsize, num), np.linspace(-ysize, ysize, num))
     zero = np.repeat(0., num ** 2)
     return _pack([zero, x.flatten(), y.flatten(), zero, zero, zero, np.repeat(1., num ** 2),
                   zero, zero, zero], device)
 
 
-def convergingbeam(zset, rin, rout, tmin, tmax, num, lscat, device=None):
+def convergingbeam(zset, rin, rout, tmin, tmax, num, lscat, device=None, rng="numpy", seed=0, first_index=0):
     """Converging sub-apertured annulus beam placed at z=zset, with Lorentzian angular scatter
     `lscat` in arcsec (sources.py:250-297)."""
+    if rng == "philox":
+        return _philox("convergingbeam", num, (zset, rin, rout, tmin, tmax, lscat), seed, first_index, device)
     rho = np.sqrt(rin ** 2 + np.random.rand(num) * (rout ** 2 - rin ** 2))
     theta = tmin + np.random.rand(num) * (tmax - tmin)
     x = rho * np.cos(theta)
@@ -167,8 +181,10 @@ def convergingbeam(zset, rin, rout, tmin, tmax, num, lscat, device=None):
     return _pack([zero, x, y, z, l, m, n, zero, zero, zero], device)
 
 
-def convergingbeam2(zset, xmin, xmax, ymin, ymax, num, lscat, device=None):
+def convergingbeam2(zset, xmin, xmax, ymin, ymax, num, lscat, device=None, rng="numpy", seed=0, first_index=0):
     """Converging rectangular beam placed at z=zset (sources.py:300-345)."""
+    if rng == "philox":
+        return _philox("convergingbeam2", num, (zset, xmin, xmax, ymin, ymax, lscat), seed, first_index, device)
     x = xmin + np.random.rand(num) * (xmax - xmin)
     y = ymin + np.random.rand(num) * (ymax - ymin)
     rho = np.sqrt(x ** 2 + y ** 2)
@@ -193,8 +209,10 @@ def rectbeam(xhalfwidth, yhalfwidth, num, device=None, rng="numpy", seed=0, firs
     return _pack([zero, x, y, zero, zero, zero, np.repeat(1., num), zero, zero, zero], device)
 
 
-def gaussianBeam(ang, num, device=None):
+def gaussianBeam(ang, num, device=None, rng="numpy", seed=0, first_index=0):
     """Point source with Gaussian angular divergence, 1-sigma `ang` (sources.py:380-413)."""
+    if rng == "philox":
+        return _philox("gaussianBeam", num, (ang,), seed, first_index, device)
     l = np.random.randn(num) * np.sin(ang) / np.sqrt(2)
     m = np.random.randn(num) * np.sin(ang) / np.sqrt(2)
     n = np.sqrt(1. - l ** 2 - m ** 2)
@@ -202,8 +220,10 @@ def gaussianBeam(ang, num, device=None):
     return _pack([zero, zero, zero, zero, l, m, n, zero, zero, zero], device)
 
 
-def fanBeam(xang, yang, num, device=None):
+def fanBeam(xang, yang, num, device=None, on_device=False):
     """XY fan of rays on a regular direction-cosine grid (sources.py:416-438)."""
+    if on_device:
+        return _philox("fanBeam", num ** 2, (xang, yang, num), 0, 0, device)
     xa, ya = np.meshgrid(np.linspace(-xang, xang, num), np.linspace(-yang, yang, num))
     l = np.sin(xa.flatten())
     m = np.sin(ya.flatten())
@@ -212,8 +232,10 @@ def fanBeam(xang, yang, num, device=None):
     return _pack([zero, zero, zero, zero, l, m, n, zero, zero, zero], device)
 
 
-def circFan(halfang, rings, arms, device=None):
+def circFan(halfang, rings, arms, device=None, on_device=False):
     """Uniformly spaced rays on a diverging cone (sources.py:441-471)."""
+    if on_device:
+        return _philox("circFan", rings * arms, (halfang, rings, arms), 0, 0, device)
     rad = np.linspace(0, halfang, rings)
     az = np.linspace(0, 2 * np.pi, arms + 1)[0:-1]
     rr, aa = np.meshgrid(rad, az)

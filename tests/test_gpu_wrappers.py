@@ -651,3 +651,43 @@ def test_zernconic_extension():
 
 
 import math  # noqa: E402
+
+
+def test_device_grid_and_extended_sources(golden):
+    """The remaining sources.py generators on the device: grid kinds equal the reference's own
+    sources.py output (positions bit for bit, direction cosines to an ulp of sin), random kinds have
+    the reference's distribution."""
+    import pyxfocus_amd.sources as sources
+    g = golden["sources"]
+    for tag, fn in (("xslit", lambda a: sources.xslit(a[0], a[1], int(a[2]), on_device=True)),
+                    ("rectArray", lambda a: sources.rectArray(a[0], a[1], int(a[2]), on_device=True)),
+                    ("fanBeam", lambda a: sources.fanBeam(a[0], a[1], int(a[2]), on_device=True)),
+                    ("circFan", lambda a: sources.circFan(a[0], int(a[1]), int(a[2]), on_device=True))):
+        rays = fn(g[tag + "/args"])
+        for k, r in zip(ALLCOLS, host(rays)):
+            w = g["%s/%s" % (tag, k)]
+            assert r.shape == w.shape, (tag, k)
+            if k in ("x", "y", "z"):
+                assert bits_equal(r, w).all(), (tag, k)
+            else:
+                assert np.abs(r - w).max() < 1e-15, (tag, k)
+    # a big grid, sharded: two halves == the whole
+    full = sources.rectArray(3., 4., 1000, on_device=True)
+    assert full[1].shape[0] == 10 ** 6 and float(full[1].max()) == 3. and float(full[2].min()) == -4.
+    n = 400_000
+    gb = sources.gaussianBeam(0.01, n, rng="philox", seed=3)
+    l, m = gb[4].cpu().numpy(), gb[5].cpu().numpy()
+    sg = np.sin(0.01) / np.sqrt(2)
+    assert abs(l.std() / sg - 1) < 5e-3 and abs(m.std() / sg - 1) < 5e-3 and abs(np.mean(l * m)) / sg ** 2 < 1e-2
+    assert float((gb[4] ** 2 + gb[5] ** 2 + gb[6] ** 2 - 1).abs().max()) < 4e-16
+    cb = sources.convergingbeam(8400., 220., 221., -.2, .3, n, 1.5, rng="philox", seed=4)
+    x, y, z, l, m, nn = [t.cpu().numpy() for t in cb[1:7]]
+    rho, th = np.hypot(x, y), np.arctan2(y, x)
+    assert rho.min() >= 220. - 1e-9 and rho.max() <= 221. + 1e-9 and th.min() >= -.2 - 1e-12 and th.max() <= .3 + 1e-12
+    assert np.all(z == 8400.) and np.abs(l ** 2 + m ** 2 + nn ** 2 - 1).max() < 1e-12
+    # rays converge toward the axis: the median pointing error is the Lorentzian scale (1.5 arcsec)
+    ang = np.arccos(-nn) - np.arctan(rho / 8400.)
+    assert abs(np.median(np.abs(ang)) / (1.5 / 3600 * np.pi / 180) - 1) < 2e-2
+    cb2 = sources.convergingbeam2(8400., 200., 220., -10., 10., n, 0., rng="philox", seed=5)
+    x, y = cb2[1].cpu().numpy(), cb2[2].cpu().numpy()
+    assert x.min() >= 200. and x.max() <= 220. and abs(y.mean()) < .05
