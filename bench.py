@@ -96,6 +96,20 @@ def cpu_baseline(gpu_chain, target_seconds=12.0):
         cases.chain_config2(be, c)
         spent += time.perf_counter() - t0
         reps += 1
+    # single-thread figure: the serial build of the same checker, 1e6-ray sample, ~3 s
+    one = None
+    try:
+        be1 = api.load_ref(omp=False) if kind == "reference" else api.load_port(omp=False)
+        n1, r1, s1 = 1_000_000, 0, 0.0
+        while s1 < 3.0 and r1 < 1000:
+            c1 = {k: v[:n1].copy() for k, v in src.items()}
+            t0 = time.perf_counter()
+            cases.chain_config2(be1, c1)
+            s1 += time.perf_counter() - t0
+            r1 += 1
+        one = n1 * r1 / s1
+    except Exception:
+        one = None
     chk = 100_000
     want = {k: v[:chk] for k, v in c.items()}
     parity = {"rays": chk, "checker": kind}
@@ -108,7 +122,7 @@ def cpu_baseline(gpu_chain, target_seconds=12.0):
             "sample": "%d x %d rays, same config-2 chain, %s, %.1f s of CPU time" % (
                 reps, n, "PyXFocus Fortran compiled with flang -O2 -fopenmp (oracle/_ref)" if kind == "reference"
                 else "C restatement oracle/pxf_oracle.c -O2 -fopenmp", spent),
-            "parity_vs_gpu": parity}
+            "one_thread_rays_per_s": one, "parity_vs_gpu": parity}
 
 
 def main():
@@ -211,6 +225,25 @@ def main():
                 "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": dom["bytes_per_ray"] * N, "avg_launch_ms": dom["avg_ms"]}
     chain_gbps = 576.0 * N * K / (sum(k["avg_ms"] for k in kern) * K * 1e-3) / 1e9
+    # measured device-to-device copy of the same nine columns ("also report against a
+    # measured copy kernel") -- what a 9R+9W stream reaches on this GPU with no arithmetic at all
+    try:
+        srcb = bundles[(K - 1) % pool]
+        dst = [torch.empty_like(srcb[1]) for _ in range(3)]
+        ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for rep in range(3):
+            if rep == 1:
+                ce[0].record()
+            for j in range(9):
+                dst[j % 3].copy_(srcb[1 + j])
+        ce[1].record()
+        torch.cuda.synchronize()
+        copy_gbps = 2 * 144.0 * N / (ce[0].elapsed_time(ce[1]) * 1e-3) / 1e9
+        del dst
+        roofline["measured_copy_GBps"] = copy_gbps
+        roofline["frac_of_measured_copy"] = dom["GBps"] / copy_gbps
+    except Exception:
+        pass
 
     # ---- the same K steps again as ONE fused launch per step (reported separately, never mixed
     # into `value`: 120 algorithmic B/ray instead of 576; bit-identical results) --------------------

@@ -332,6 +332,27 @@ size_t pxf_select_workspace_bytes(void);
 int pxf_kth_values(const double *v, int64_t num, const int64_t *k, int32_t nk, double *out_dev,
                    void *workspace, pxf_stream_t stream);
 
+/* ---- wavefront sensing: reconstruct.f95 ---------------------------------------------------------
+ * Grids are Fortran-ordered like the reference's arrays: a(xi,yi) = a[xi + xdim*yi] (device memory).
+ *
+ * southwellbin(x,y,l,m,num,binsize,xang,yang,phase,xdim,ydim)               reconstruct.f95:139-187
+ * Bins l, m by ray position on an xdim x ydim lenslet grid of pitch `binsize`; per bin the mean
+ * cosine becomes a slope tan(asin(mean)); empty bins get 100. in xang, yang AND phase (other phase
+ * cells are set to 0).  Rays outside the grid are dropped (the reference indexes out of bounds).
+ * Sums are accumulated with atomics (order-nondeterministic, like the reference's OpenMP loop).
+ * `workspace`: pxf_southwellbin_workspace_bytes(xdim, ydim) bytes of device memory. */
+size_t pxf_southwellbin_workspace_bytes(int32_t xdim, int32_t ydim);
+int pxf_southwellbin(const double *x, const double *y, const double *l, const double *m, int64_t num,
+                     double binsize, double *xang, double *yang, double *phase, int32_t xdim, int32_t ydim,
+                     void *workspace, pxf_stream_t stream);
+/* reconstruct(xang,yang,xdim,ydim,criteria,h,phase,phasec,maxiter)           reconstruct.f95:1-131
+ * Southwell SOR in the reference's Gauss-Seidel order (executed by anti-diagonals: identical
+ * updates).  xang, yang, phase are updated in place as in the reference (isolated lenslets are set
+ * to 100.; phase ends equal to phasec); phasec receives the reconstructed phase.  `sweeps_dev`
+ * (device int32, may be NULL) receives the number of sweeps performed. */
+int pxf_reconstruct(double *xang, double *yang, int32_t xdim, int32_t ydim, double criteria, double h,
+                    double *phase, double *phasec, int32_t maxiter, int32_t *sweeps_dev, pxf_stream_t stream);
+
 /* ---- sources.py on the device ------------------------------------------------------------------ */
 
 /* Counter-based Philox4x32-10 keyed on (seed, first_index + i): the bundle is a pure function of

@@ -44,6 +44,19 @@ def _cols(*arrs):
     return [_f64(a) for a in arrs], n
 
 
+def _g64(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _grid2(*arrs):
+    """Shape check for the Fortran-ordered 2-D arrays of reconstruct.f95 (f2py would raise/copy)."""
+    shp = arrs[0].shape
+    for a in arrs:
+        if a.ndim != 2 or a.shape != shp or a.dtype != np.float64 or not a.flags.f_contiguous:
+            raise TypeError("expected Fortran-contiguous float64 arrays of one (xdim, ydim) shape")
+    return int(shp[0]), int(shp[1])
+
+
 def _i32(a):
     a = np.ascontiguousarray(np.asarray(a), dtype=np.int32)
     return a, a.ctypes.data_as(_ip)
@@ -309,6 +322,21 @@ def load_port(omp=False):
         if f_zrot(*p, num, c1p, r1p, a1p, len(c1), c2p, r2p, a2p, len(c2), rad, rot) != 0:
             raise ValueError("tracezernrot: (rorder, aorder) outside the reference's radial table")
 
+    f_swb = sig("orc_southwellbin", *[P] * 4, i64, d, *[P] * 3, i32, i32)
+    f_rec = sig("orc_reconstruct", P, P, i32, i32, d, d, P, P, i32, restype=i32)
+
+    def southwellbin(x, y, l, m, binsize, xdim, ydim):
+        p, num = _cols(x, y, l, m)
+        out = [np.zeros((xdim, ydim), order="F") for _ in range(3)]
+        f_swb(*p, num, binsize, *[_g64(a) for a in out], xdim, ydim)
+        return tuple(out)
+
+    def reconstruct(xang, yang, criteria, h, phase, maxiter):
+        xdim, ydim = _grid2(xang, yang, phase)
+        phasec = np.zeros((xdim, ydim), order="F")
+        reconstruct.sweeps = f_rec(_g64(xang), _g64(yang), xdim, ydim, criteria, h, _g64(phase), _g64(phasec), maxiter)
+        return phasec
+
     def wolter_params(r0, z0, psi=1.):
         o = [C.c_double() for _ in range(3)]
         f_par(r0, z0, psi, *[C.byref(v) for v in o])
@@ -330,6 +358,7 @@ def load_port(omp=False):
                                  zernphase=zernphase, tracezernrot=tracezernrot),
         transformationsf=SimpleNamespace(transform=transform, itransform=itransform, reflect=reflect,
                                          radgrat=radgrat, radgratw=radgratw, grat=grat, refract=refract),
+        reconstruct=SimpleNamespace(southwellbin=southwellbin, reconstruct=reconstruct),
         wolter_params=wolter_params)
 
 
@@ -337,7 +366,7 @@ def load_port(omp=False):
 def ref_available(omp=False):
     sfx = "_omp" if omp else ""
     return all(os.path.exists(os.path.join(HERE, "_ref", "libpxfref_%s%s.so" % (m, sfx)))
-               for m in ("surfacesf", "woltsurf", "zernsurf", "transformationsf"))
+               for m in ("surfacesf", "woltsurf", "zernsurf", "transformationsf", "reconstruct"))
 
 
 def load_ref(omp=False):
@@ -346,7 +375,7 @@ def load_ref(omp=False):
         raise FileNotFoundError("oracle/_ref not built (needs /root/reference + flang: make -C oracle ref)")
     sfx = "_omp" if omp else ""
     L = {m: C.CDLL(os.path.join(HERE, "_ref", "libpxfref_%s%s.so" % (m, sfx)))
-         for m in ("surfacesf", "woltsurf", "zernsurf", "transformationsf")}
+         for m in ("surfacesf", "woltsurf", "zernsurf", "transformationsf", "reconstruct")}
 
     def fn(mod, name):
         f = getattr(L[mod], name + "_")
@@ -502,8 +531,28 @@ def load_ref(omp=False):
         p, num = _cols(l, m, n, ux, uy, uz)
         f_rfr(*p, num32(num), dref(n1), dref(n2))
 
+    f_swb, f_rec = fn("reconstruct", "southwellbin"), fn("reconstruct", "reconstruct")
+
+    def southwellbin(x, y, l, m, binsize, xdim, ydim):
+        # subroutine southwellbin(x,y,l,m,num,binsize,xang,yang,phase,xdim,ydim)   reconstruct.f95:139
+        # (out-of-grid rays index out of bounds in the reference: callers keep rays inside)
+        p, num = _cols(x, y, l, m)
+        out = [np.zeros((xdim, ydim), order="F") for _ in range(3)]
+        f_swb(*p, num32(num), dref(binsize), *[_g64(a) for a in out], C.byref(C.c_int32(xdim)),
+              C.byref(C.c_int32(ydim)))
+        return tuple(out)
+
+    def reconstruct(xang, yang, criteria, h, phase, maxiter):
+        # subroutine reconstruct(xang,yang,xdim,ydim,criteria,h,phase,phasec,maxiter)  reconstruct.f95:1
+        xdim, ydim = _grid2(xang, yang, phase)
+        phasec = np.zeros((xdim, ydim), order="F")
+        f_rec(_g64(xang), _g64(yang), C.byref(C.c_int32(xdim)), C.byref(C.c_int32(ydim)), dref(criteria), dref(h),
+              _g64(phase), _g64(phasec), C.byref(C.c_int32(maxiter)))
+        return phasec
+
     return SimpleNamespace(
         kind="reference", omp=omp,
+        reconstruct=SimpleNamespace(southwellbin=southwellbin, reconstruct=reconstruct),
         surfacesf=SimpleNamespace(flat=mk9("surfacesf", "flat", 0), flatopd=flatopd,
                                   conic=mk9("surfacesf", "conic", 2),
                                   conicopd=mk10("surfacesf", "conicopd", 3),

@@ -414,3 +414,34 @@ def rms_centroid(x, y):
     """analyses.py:16-30 (unweighted)."""
     cx, cy = np.average(x), np.average(y)
     return float(np.sqrt(np.average((x - cx) ** 2 + (y - cy) ** 2)))
+
+
+# ---- wavefront sensing (reconstruct.f95) ----------------------------------------------------
+def wavefront_cases():
+    """(tag, xdim, ydim, binsize, x, y, l, m): rays filling an elliptical pupil inside an
+    xdim x ydim lenslet grid (so the corners are invalid lenslets), slopes of a smooth wavefront
+    plus noise.  Even, odd and mixed grid sizes take both bin formulas of southwellbin."""
+    out = []
+    for tag, xdim, ydim, bs, n, seed in (("g20x20", 20, 20, 1.0, 6000, 1), ("g21x17", 21, 17, 0.5, 5000, 2),
+                                         ("g16x33", 16, 33, 2.0, 8000, 3), ("g9x9_sparse", 9, 9, 1.0, 60, 4)):
+        rng = np.random.default_rng(1000 + seed)
+        ax, ay = (xdim / 2 - 2) * bs, (ydim / 2 - 2) * bs
+        x, y = rng.uniform(-ax, ax, n), rng.uniform(-ay, ay, n)
+        keep = (x / ax) ** 2 + (y / ay) ** 2 < 1
+        x, y = np.ascontiguousarray(x[keep]), np.ascontiguousarray(y[keep])
+        l = 1e-4 * np.sin(x / (3 * bs)) + 2e-5 * y / ay + 1e-6 * rng.normal(size=len(x))
+        m = 2e-4 * np.cos(y / (4 * bs)) - 3e-5 * x / ax + 1e-6 * rng.normal(size=len(x))
+        out.append((tag, xdim, ydim, bs, x, y, np.ascontiguousarray(l), np.ascontiguousarray(m)))
+    return out
+
+
+def wavefront_run(be, case, criteria=1e-12, maxiter=10000):
+    """southwellbin -> reconstruct as analyses.wavefront does (analyses.py:305-334: slopes swapped,
+    reconstruct(y, x, 1e-12, dx, phase)).  Returns dict of the grids after each stage."""
+    tag, xdim, ydim, bs, x, y, l, m = case
+    xang, yang, phase = be.reconstruct.southwellbin(x, y, l, m, bs, xdim, ydim)
+    res = {"bin_xang": xang.copy(order="F"), "bin_yang": yang.copy(order="F"), "bin_phase": phase.copy(order="F")}
+    a, b, ph = yang.copy(order="F"), xang.copy(order="F"), phase.copy(order="F")
+    res["phasec"] = be.reconstruct.reconstruct(a, b, criteria, bs, ph, maxiter)
+    res["rec_xang"], res["rec_yang"], res["rec_phase"] = a, b, ph
+    return res

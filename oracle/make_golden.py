@@ -230,6 +230,19 @@ def main():
     np.savez_compressed(os.path.join(OUT, "sources.npz"), **blob)
     print("sources:", len(blob), "arrays")
 
+    # ---- wavefront sensing: southwellbin + reconstruct through the compiled reconstruct.f95 ----
+    blob = {}
+    for case in cases.wavefront_cases():
+        tag, xdim, ydim, bs, x, y, l, m = case
+        blob[tag + "/dims"] = np.array([xdim, ydim])
+        blob[tag + "/binsize"] = np.array(bs)
+        for k, v in zip("xylm", (x, y, l, m)):
+            blob["%s/in_%s" % (tag, k)] = v
+        for k, v in cases.wavefront_run(ref, case).items():
+            blob["%s/%s" % (tag, k)] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "wavefront.npz"), **blob)
+    print("wavefront:", len(blob), "arrays")
+
 
 if __name__ == "__main__":
     main()

@@ -1315,3 +1315,103 @@ int orc_tracezernrot(double *x, double *y, double *z, const double *l, const dou
     free(rnm);
     return 0;
 }
+
+/* ---- wavefront sensing: reconstruct.f95 ------------------------------------------------------
+ * Arrays are Fortran-ordered (xdim fastest): a(xi,yi) = a[xi + xdim*yi], xi,yi 0-based here. */
+
+/* southwellbin, reconstruct.f95:139-187.  Bins ray slopes into a lenslet grid and converts the mean
+ * direction cosine of each bin to a slope tan(asin(.)); empty bins get the sentinel 100.  The
+ * reference indexes out of bounds for rays outside the grid (undefined); here they are skipped.
+ * xang/yang are accumulated from zero (the reference's intent(out) arrays are "init to 0" by its
+ * caller, :137). */
+void orc_southwellbin(const double *x, const double *y, const double *l, const double *m, int64_t num,
+                      double binsize, double *xang, double *yang, double *phase, int32_t xdim, int32_t ydim)
+{
+    int64_t nb = (int64_t)xdim * ydim;
+    int32_t *accum = (int32_t *)calloc((size_t)nb, sizeof(int32_t));
+    for (int64_t b = 0; b < nb; b++) {
+        xang[b] = 0.;
+        yang[b] = 0.;
+        phase[b] = 0.;
+    }
+    for (int64_t i = 0; i < num; i++) {
+        long xb, yb; /* 0-based (the Fortran's 1-based index minus one) */
+        if (xdim % 2 == 0)
+            xb = (long)floor(x[i] / binsize) + xdim / 2 + 1;
+        else
+            xb = (long)floor((x[i] + binsize / 2) / binsize) + (xdim - 1) / 2;
+        if (ydim % 2 == 0)
+            yb = (long)floor(y[i] / binsize) + ydim / 2 + 1;
+        else
+            yb = (long)floor((y[i] + binsize / 2) / binsize) + (ydim - 1) / 2;
+        if (xb < 0 || xb >= xdim || yb < 0 || yb >= ydim) continue;
+        xang[xb + (int64_t)xdim * yb] += l[i];
+        yang[xb + (int64_t)xdim * yb] += m[i];
+        accum[xb + (int64_t)xdim * yb] += 1;
+    }
+    for (int64_t b = 0; b < nb; b++) {
+        if (accum[b] == 0) {
+            phase[b] = 100.;
+            xang[b] = 100.;
+            yang[b] = 100.;
+        } else {
+            xang[b] = tan(asin(xang[b] / accum[b]));
+            yang[b] = tan(asin(yang[b] / accum[b]));
+        }
+    }
+    free(accum);
+}
+
+/* reconstruct, reconstruct.f95:1-131.  Successive over-relaxation (Gauss-Seidel order: xi outer,
+ * yi inner) of the Southwell geometry; 100. marks invalid lenslets.  Returns the number of sweeps. */
+int32_t orc_reconstruct(double *xang, double *yang, int32_t xdim, int32_t ydim, double criteria, double h,
+                        double *phase, double *phasec, int32_t maxiter)
+{
+    const double pi = (double)3.1415926535897931f; /* default-real literal, :13 */
+    const double w = 2 / (1 + sin(pi / (sqrt((double)xdim * (double)ydim) + 1)));
+    const int64_t nb = (int64_t)xdim * ydim;
+    const int64_t sx = 1, sy = xdim;
+    int32_t counter = 0, sweeps = 0;
+    for (int64_t b = 0; b < nb; b++) phasec[b] = phase[b];
+    for (;;) {
+        double rms = 0.;
+        int32_t nannum = 0;
+        for (int32_t xi = 1; xi < xdim - 1; xi++) {
+            for (int32_t yi = 1; yi < ydim - 1; yi++) {
+                const int64_t o = xi * sx + yi * sy;
+                if (phasec[o] == 100.) continue;
+                double yplus = yang[o + sy], yneg = yang[o - sy], xplus = xang[o + sx], xneg = xang[o - sx];
+                if (yplus == 100.) yplus = -yang[o];
+                if (yneg == 100.) yneg = -yang[o];
+                if (xplus == 100.) xplus = -xang[o];
+                if (xneg == 100.) xneg = -xang[o];
+                const double bk = .5 * (yplus - yneg + xplus - xneg) * h;
+                double goodpix = 4.;
+                double pyplus = phasec[o + sy], pyneg = phasec[o - sy], pxplus = phasec[o + sx], pxneg = phasec[o - sx];
+                if (pyplus == 100.) { pyplus = 0.; goodpix -= 1; }
+                if (pyneg == 100.) { pyneg = 0.; goodpix -= 1; }
+                if (pxplus == 100.) { pxplus = 0.; goodpix -= 1; }
+                if (pxneg == 100.) { pxneg = 0.; goodpix -= 1; }
+                const double psum = pyplus + pyneg + pxplus + pxneg;
+                if (goodpix == 0.) {
+                    phasec[o] = 100.;
+                    phase[o] = 100.;
+                    xang[o] = 100.;
+                    yang[o] = 100.;
+                    continue;
+                }
+                phasec[o] = phasec[o] + w * ((psum + bk) / goodpix - phasec[o]);
+                nannum += 1;
+                const double df = phasec[o] - phase[o];
+                rms = rms + df * df;
+            }
+        }
+        rms = sqrt(rms / nannum);
+        for (int64_t b = 0; b < nb; b++) phase[b] = phasec[b];
+        sweeps++;
+        if (rms < criteria) break;
+        counter++;
+        if (counter > maxiter) break;
+    }
+    return sweeps;
+}

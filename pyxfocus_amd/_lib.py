@@ -87,6 +87,9 @@ _SIGS = {
     "pxf_kth_values": [_P, _i64, C.POINTER(C.c_int64), _i32, _P, _P, _P],
     "pxf_source": [_i32, _PP, _i64, _d, _d, _d, _d, _u64, _u64, _P],
     "pxf_source_ex": [_i32, _PP, _i64, _i64, _DP, _u64, _u64, _P],
+    "pxf_southwellbin_workspace_bytes": [_i32, _i32],
+    "pxf_southwellbin": [_P, _P, _P, _P, _i64, _d, _P, _P, _P, _i32, _i32, _P, _P],
+    "pxf_reconstruct": [_P, _P, _i32, _i32, _d, _d, _P, _P, _i32, _P, _P],
     "pxf_program_run": [_P, _i32, _PP, _i64, _P],
     "pxf_program_params": [_P, _i32, _DP, C.POINTER(C.c_int32)],
     "pxf_program_run_segments": [_P, _i32, _P, _i32, _i64, _PP, _i64, _P],
@@ -95,7 +98,7 @@ _SIGS = {
 }
 _RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,
             "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t,
-            "pxf_select_workspace_bytes": C.c_size_t}
+            "pxf_select_workspace_bytes": C.c_size_t, "pxf_southwellbin_workspace_bytes": C.c_size_t}
 
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -13,7 +13,9 @@
 // coefficient per Newton step.  Here the (coeff, axial, az) list is folded on the host into a
 // dense matrix C[axial][az], passed by value in the kernel arguments and staged in LDS; P_n and
 // P'_n come from the three-term recurrences, generated on the fly inside the double loop over
-// (axial, az) so no per-thread array is ever indexed at run time.
+// (axial, az) so no per-thread array is ever indexed at run time; the recurrence coefficients
+// (2n+3)/(n+2), (n+1)/(n+2) sit in LDS and per-iteration reciprocals are shared, so a Newton step
+// costs 6 IEEE divides instead of ~30 (parity for these surfaces is to 1e-10, see tests/util.py).
 #include <math.h>
 
 #include "pxf_kernel.h"
@@ -75,9 +77,11 @@ struct LLOp {
     int ka, kt;              // highest axial / azimuthal order present
     double cmat[kLLMax];     // C[i*(kt+1)+j], by value in the kernel-argument segment
 
+    // LDS: [0,kLLMax) the matrix C, then the recurrence coefficients a_n=(2n+3)/(n+2), b_n=(n+1)/(n+2)
+    // of P_{n+2} = a_n x P_{n+1} - b_n P_n (so the inner loops multiply instead of dividing)
     __device__ __forceinline__ double *lds() const
     {
-        __shared__ double s_c[kLLMax];
+        __shared__ double s_c[3 * kLLMax];
         return s_c;
     }
     __device__ __forceinline__ void prologue() const
@@ -85,6 +89,10 @@ struct LLOp {
         double *s = lds();
         const int nn = (ka + 1) * (kt + 1);
         for (int i = threadIdx.x; i < nn; i += kBlock) s[i] = cmat[i];
+        for (int i = threadIdx.x; i < kLLMax; i += kBlock) {
+            s[kLLMax + i] = (double)(2 * i + 3) / (double)(i + 2);
+            s[2 * kLLMax + i] = (double)(i + 1) / (double)(i + 2);
+        }
         __syncthreads();
     }
 
@@ -92,17 +100,19 @@ struct LLOp {
     __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
     {
         const double *__restrict__ cm = lds();
+        const double *__restrict__ ra = cm + kLLMax, *__restrict__ rb = cm + 2 * kLLMax;
         double *c = r[0].c;
         double Fx = 0., Fy = 0., Fz = 0.;
         bool act = sel[0];
+        const double izh = 1. / zhalf, tdp = 2 / dphi;   // wave-uniform, hoisted
         for (int it = 0; act && it < kNewtonCap; it++) {
             const double x = c[X], y = c[Y], z = c[Z];
             const double ang = atan2(y, x);
-            const double zarg = (z - zmid) / zhalf;
-            const double targ = 2 * ang / dphi;
+            const double zarg = (z - zmid) * izh;
+            const double targ = ang * tdp;
             // legendre() clamps |x|>1 to sign(x); legendrep() returns 0 there (specialFunctions.f95:345-349,384-386)
-            const double zc = fabs(zarg) > 1. ? zarg / fabs(zarg) : zarg;
-            const double tc = fabs(targ) > 1. ? targ / fabs(targ) : targ;
+            const double zc = fabs(zarg) > 1. ? copysign(1., zarg) : zarg;
+            const double tc = fabs(targ) > 1. ? copysign(1., targ) : targ;
             const bool zin = !(fabs(zarg) > 1.), tin = !(fabs(targ) > 1.);
             double add = 0., addt = 0., addzz = 0.;
             double pz0 = 1., pz1 = zc, dz0 = 0., dz1 = 1.;  // P_i, P_{i+1}, P'_i, P'_{i+1} in zarg
@@ -114,7 +124,7 @@ struct LLOp {
                     const double cij = cm[i * (kt + 1) + j];
                     s0 += cij * pt0;
                     s1 += cij * (tin ? dt0 : 0.);
-                    const double pn = ((2 * j + 3) * tc * pt1 - (j + 1) * pt0) / (j + 2);  // P_{j+2}
+                    const double pn = ra[j] * tc * pt1 - rb[j] * pt0;  // P_{j+2}
                     const double dn = dt0 + (2 * j + 3) * pt1;                            // P'_{j+2}
                     pt0 = pt1;
                     pt1 = pn;
@@ -124,7 +134,7 @@ struct LLOp {
                 add += Pz * s0;
                 addt += Pz * s1;
                 addzz += dPz * s0;
-                const double pn = ((2 * i + 3) * zc * pz1 - (i + 1) * pz0) / (i + 2);
+                const double pn = ra[i] * zc * pz1 - rb[i] * pz0;
                 const double dn = dz0 + (2 * i + 3) * pz1;
                 pz0 = pz1;
                 pz1 = pn;
@@ -132,28 +142,33 @@ struct LLOp {
                 dz1 = dn;
             }
             const double r2 = y * y + x * x;
-            const double addx = -(addt * (2 / dphi) * (y / r2));
-            const double addy = addt * (2 / dphi) * (x / r2);
-            const double addz = addzz * 2 / zspan;
-            const double rr = sqrt(x * x + y * y);
+            const double ir2 = 1. / r2;
+            const double addx = -(addt * tdp * (y * ir2));
+            const double addy = addt * tdp * (x * ir2);
+            const double addz = addzz * (2 / zspan);
+            const double rr = sqrt(r2);
+            // x/rr, y/rr stay IEEE divides: they set the Newton trajectory at first order, and the
+            // secondary's F cancels to ~1e-8 (e^2(d+z)^2 - z^2), so a 1-ulp change of the path moves
+            // the converged z by ~2e-9 -- more than the 1e-10 parity these surfaces are held to
+            const double xr = x / rr, yr = y / rr;
             const double G = rr + add;
             double F;
             if (KIND == 0) {
                 F = -(G * G - pp - twop * z - cst);
-                Fx = -(2 * G * (x / rr + addx));
-                Fy = -(2 * G * (y / rr + addy));
+                Fx = -(2 * G * (xr + addx));
+                Fy = -(2 * G * (yr + addy));
                 Fz = twop - 2 * G * addz;
             } else if (KIND == 1) {
                 const double dz = d + z;
                 F = -(G * G - e2 * (dz * dz) + z * z);
-                Fx = -(2 * G * (x / rr + addx));
-                Fy = -(2 * G * (y / rr + addy));
+                Fx = -(2 * G * (xr + addx));
+                Fy = -(2 * G * (yr + addy));
                 Fz = twoe2 * dz - 2 * z - 2 * G * addz;
             } else {
                 const double zz = z - zfoc;
                 F = zz * zz / aa2 + G * G / bb2 - 1.;
-                Fx = 2 * G / bb2 * (x / rr + addx);
-                Fy = 2 * G / bb2 * (y / rr + addy);
+                Fx = 2 * G / bb2 * (xr + addx);
+                Fy = 2 * G / bb2 * (yr + addy);
                 Fz = 2 * zz / aa2 + (2 * G / bb2) * addz;
             }
             const double Fp = Fx * c[L] + Fy * c[M] + Fz * c[N];

@@ -356,6 +356,67 @@ def radgratw(x, y, l, m, n, wave, dpermm, order, mask=None):
     _call("pxf_radgratw", (x, y, l, m, n, wave), (float(dpermm), float(order)), mask)
 
 
+# ---- reconstruct.f95 (f2py module `reconstruct`) -------------------------------------------------
+def _fgrid(xdim, ydim, dev):
+    """(xdim, ydim) float64 tensor laid out like a Fortran array (xdim fastest)."""
+    return torch.empty((ydim, xdim), dtype=torch.float64, device=dev).t()
+
+
+def _check_fgrids(what, *g):
+    shp = g[0].shape
+    for t in g:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.dim() == 2):
+            raise TypeError("%s: grids must be 2-D float64 tensors on a ROCm device" % what)
+        if t.shape != shp or t.device != g[0].device or not t.t().is_contiguous():
+            raise ValueError("%s: grids must share one (xdim, ydim) shape and be Fortran-ordered "
+                             "(see native.fgrid)" % what)
+    return int(shp[0]), int(shp[1])
+
+
+def fgrid(a, device=None):
+    """Device copy of a 2-D array in the Fortran order the reconstruct entries expect."""
+    t = torch.as_tensor(a, dtype=torch.float64)
+    out = _fgrid(t.shape[0], t.shape[1], device if device is not None else
+                 (t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())))
+    out.copy_(t)
+    return out
+
+
+def southwellbin(x, y, l, m, binsize, xdim, ydim):
+    """reconstruct.southwellbin(x,y,l,m,binsize,xdim,ydim) -> (xang, yang, phase)   reconstruct.f95:139"""
+    fused.flush()
+    num, dev = _check_cols((x, y, l, m), "pxf_southwellbin")
+    xdim, ydim = int(xdim), int(ydim)
+    if xdim < 1 or ydim < 1:
+        raise ValueError("southwellbin: xdim, ydim must be positive")
+    out = [_fgrid(xdim, ydim, dev) for _ in range(3)]
+    h = _lib.lib()
+    ws = torch.empty(max(1, h.pxf_southwellbin_workspace_bytes(xdim, ydim)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = h.pxf_southwellbin(x.data_ptr(), y.data_ptr(), l.data_ptr(), m.data_ptr(), num, float(binsize),
+                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), xdim, ydim,
+                                ws.data_ptr(), _stream(dev))
+    _lib.check(rc, "pxf_southwellbin")
+    return tuple(out)
+
+
+def reconstruct(xang, yang, criteria, h, phase, maxiter, return_sweeps=False):
+    """reconstruct.reconstruct(xang,yang,criteria,h,phase,maxiter) -> phasec   reconstruct.f95:1.
+    xang, yang, phase are updated in place, as the f2py intent(inout) arrays are."""
+    fused.flush()
+    xdim, ydim = _check_fgrids("pxf_reconstruct", xang, yang, phase)
+    dev = xang.device
+    phasec = _fgrid(xdim, ydim, dev)
+    sw = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_reconstruct(xang.data_ptr(), yang.data_ptr(), xdim, ydim, float(criteria), float(h),
+                                        phase.data_ptr(), phasec.data_ptr(), int(maxiter), sw.data_ptr(),
+                                        _stream(dev))
+    _lib.check(rc, "pxf_reconstruct")
+    return (phasec, int(sw.item())) if return_sweeps else phasec
+
+
+reconstruct_mod = SimpleNamespace(southwellbin=southwellbin, reconstruct=reconstruct)
 surfacesf = SimpleNamespace(flat=flat, flatopd=flatopd, conic=conic, conicopd=conicopd,
                             tracesphere=tracesphere, tracesphereopd=tracesphereopd, tracecyl=tracecyl,
                             tracecylopd=tracecylopd, cylconic=cylconic, paraxial=paraxial, paraxialy=paraxialy,

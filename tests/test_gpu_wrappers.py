@@ -18,6 +18,10 @@ def host(rays):
     return [r.cpu().numpy() for r in rays]
 
 
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to("cuda")
+
+
 def assert_rays(got, g, prefix, exact=True, tol=0.):
     for k, a in zip(ALLCOLS, host(got)):
         w = g["%s/%s" % (prefix, k)]
@@ -691,3 +695,56 @@ def test_device_grid_and_extended_sources(golden):
     cb2 = sources.convergingbeam2(8400., 200., 220., -10., 10., n, 0., rng="philox", seed=5)
     x, y = cb2[1].cpu().numpy(), cb2[2].cpu().numpy()
     assert x.min() >= 200. and x.max() <= 220. and abs(y.mean()) < .05
+
+
+def test_wavefront_southwellbin_and_reconstruct(golden):
+    """reconstruct.f95 on the device.  Binning: same valid/invalid lenslets, means to 1e-12 (the
+    sums are accumulated with atomics).  Reconstruction from the REFERENCE's binned slopes: the
+    anti-diagonal Gauss-Seidel sweep performs the reference's updates bit for bit."""
+    from oracle import cases
+    from pyxfocus_amd import native
+    g = golden["wavefront"]
+    for case in cases.wavefront_cases():
+        tag, xdim, ydim, bs = case[:4]
+        x, y, l, m = [dev(v) for v in case[4:]]
+        xang, yang, phase = native.southwellbin(x, y, l, m, bs, xdim, ydim)
+        for name, t in (("bin_xang", xang), ("bin_yang", yang), ("bin_phase", phase)):
+            got, want = t.cpu().numpy(), g["%s/%s" % (tag, name)]
+            assert got.shape == want.shape == (xdim, ydim)
+            assert np.array_equal(got == 100., want == 100.), (tag, name)
+            assert np.abs(got - want).max() <= 1e-12 * max(1., np.abs(want[want != 100.]).max()), (tag, name)
+        # analyses.wavefront's call: reconstruct(yang, xang, 1e-12, dx, phase)  (analyses.py:325)
+        a, b, ph = [native.fgrid(g["%s/bin_%s" % (tag, k)]) for k in ("yang", "xang", "phase")]
+        phasec, sweeps = native.reconstruct(a, b, 1e-12, bs, ph, 10000, return_sweeps=True)
+        assert sweeps > 3
+        for name, t in (("phasec", phasec), ("rec_xang", a), ("rec_yang", b), ("rec_phase", ph)):
+            assert bits_equal(t.cpu().numpy(), g["%s/%s" % (tag, name)]).all(), (tag, name, sweeps)
+    # rays outside the grid are dropped, not written out of bounds
+    far = dev(np.array([1e9, -1e9, np.nan, 0.25]))
+    one = dev(np.array([0., 0., 0., 1e-3]))
+    xa, ya, ph = native.southwellbin(far, one * 0, one, one, 1.0, 8, 8)
+    assert int((ph != 100.).sum()) == 1 and abs(float(xa[xa != 100.][0]) - np.tan(np.arcsin(1e-3))) < 1e-18
+
+
+def test_wavefront_large_grid_paths():
+    """Grids beyond the LDS-resident sizes: global-atomic binning (> 3072 bins) and the
+    global-memory phase grid (> 160 KB), checked against the oracle on the same data."""
+    from oracle import api
+    from pyxfocus_amd import native
+    port = api.load_port()
+    rng = np.random.default_rng(5)
+    xdim, ydim, bs, n = 150, 160, 0.5, 400_000
+    x, y = rng.uniform(-36., 36., n), rng.uniform(-38., 38., n)
+    keep = (x / 36.) ** 2 + (y / 38.) ** 2 < 1
+    x, y = np.ascontiguousarray(x[keep]), np.ascontiguousarray(y[keep])
+    l, m = 1e-4 * np.sin(x / 9.), 2e-4 * np.cos(y / 7.)
+    wx, wy, wp = port.reconstruct.southwellbin(x, y, l, m, bs, xdim, ydim)
+    gx, gy, gp = native.southwellbin(dev(x), dev(y), dev(l), dev(m), bs, xdim, ydim)
+    assert np.array_equal(gp.cpu().numpy(), wp)
+    assert np.abs(gx.cpu().numpy() - wx).max() < 1e-15 and np.abs(gy.cpu().numpy() - wy).max() < 1e-15
+    a, b, ph = wy.copy(order="F"), wx.copy(order="F"), wp.copy(order="F")
+    want = port.reconstruct.reconstruct(a, b, 1e-9, bs, ph, 300)
+    ga, gb, gph = native.fgrid(wy), native.fgrid(wx), native.fgrid(wp)
+    got, sweeps = native.reconstruct(ga, gb, 1e-9, bs, gph, 300, return_sweeps=True)
+    assert sweeps == port.reconstruct.reconstruct.sweeps
+    assert bits_equal(got.cpu().numpy(), want).all() and bits_equal(gph.cpu().numpy(), ph).all()

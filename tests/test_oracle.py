@@ -112,3 +112,27 @@ def test_oracle_edge_semantics(port):
     e = [np.zeros(0) for _ in range(9)]
     port.woltsurf.wolterprimary(*e, 220., 8400., 1.)
     port.transformationsf.transform(*e, 1., 2., 3., .1, .2, .3)
+
+
+def test_wavefront_port_matches_reference_goldens(port, golden):
+    """southwellbin + reconstruct (reconstruct.f95): the C restatement reproduces the compiled
+    reference bit for bit, including which lenslets are invalid (100.) and the isolated ones the
+    sweep discards."""
+    from oracle import cases
+    g = golden["wavefront"]
+    for case in cases.wavefront_cases():
+        tag = case[0]
+        for k, v in zip("xylm", case[4:]):
+            assert np.array_equal(g["%s/in_%s" % (tag, k)], v), (tag, k)      # generator is deterministic
+        got = cases.wavefront_run(port, case)
+        for k, v in got.items():
+            assert np.array_equal(v, g["%s/%s" % (tag, k)]), (tag, k)
+        assert (got["phasec"] == 100.).any() and (got["phasec"] != 100.).any()
+
+
+def test_wavefront_port_matches_reference_live(port, ref):
+    from oracle import cases
+    for case in cases.wavefront_cases():
+        a, b = cases.wavefront_run(port, case, criteria=1e-9, maxiter=50), cases.wavefront_run(ref, case, 1e-9, 50)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (case[0], k)
