@@ -243,6 +243,35 @@ def main():
     np.savez_compressed(os.path.join(OUT, "wavefront.npz"), **blob)
     print("wavefront:", len(blob), "arrays")
 
+    # ---- host design helpers: the reference's own conicsolve.py (imported by path; the pyplot star
+    # import it performs needs a non-interactive backend), plus transformations.skew ---------------
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    con = _load_by_path("refconicsolve", os.path.join(REF, "conicsolve.py"))
+    blob = {}
+    z = np.linspace(8400., 8500., 7)
+    for tag, (r0, z0, psi) in (("a", (220., 8400., 1.)), ("b", (150., 10000., 2.5)), ("c", (610., 8400., .5))):
+        blob[tag + "/par"] = np.array([r0, z0, psi])
+        blob[tag + "/primrad"] = con.primrad(z, r0, z0, psi)
+        blob[tag + "/secrad"] = con.secrad(z - 200., r0, z0, psi)
+        blob[tag + "/woltparam"] = np.array(con.woltparam(r0, z0))
+        blob[tag + "/primfocus"] = np.array(con.primfocus(r0, z0))
+        blob[tag + "/primsag"] = np.array(con.primsag(z0 + 100., r0, z0))
+        blob[tag + "/secsag"] = np.array(con.secsag(z0 - 100., z0 - 5., r0, z0, psi))
+        blob[tag + "/rGoal_to_rMax"] = np.array(con.rGoal_to_rMax(r0 + 1., z0, z0 + 100.))
+        blob[tag + "/wsRMS"] = np.array(con.wsRMS(psi, 1e-3, 6.5e-3, 100., z0))
+        blob[tag + "/wsFoc"] = np.array(con.wsFoc(np.array([0., 1., 5.]), psi, 100., z0, 6.5e-3))
+        S = 50000.
+        blob[tag + "/ellipsoidFunction"] = np.array(con.ellipsoidFunction(S, psi, r0, z0))
+        blob[tag + "/ellipsoidRad"] = con.ellipsoidRad(S, psi, r0, z0, z)
+        blob[tag + "/ehSecRad"] = con.ehSecRad(S, psi, r0, z0, z - 200.)
+        blob[tag + "/ellipsoidSag"] = np.array(con.ellipsoidSag(S, psi, r0, z0, z0 + 100., z0))
+        P, a, b, e, f = con.ellipsoidFunction(S, psi, r0, z0)
+        blob[tag + "/solveS"] = np.array(con.solveS(P, a, b, e, f, r0 + .3, .2, z0 + 50., 1e-3, -2e-3,
+                                                    -np.sqrt(1 - 5e-6)))
+    blob["skew"] = tran.skew(np.array([1., -2., 3.5]))
+    np.savez_compressed(os.path.join(OUT, "design.npz"), **blob)
+    print("design:", len(blob), "arrays")
+
 
 if __name__ == "__main__":
     main()

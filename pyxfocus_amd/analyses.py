@@ -181,6 +181,50 @@ def hpd(rays, weights=None, cent=True):
     return (lo + hi) * .5 * 2.
 
 
+def hpdY(rays, weights=None):
+    """HPD in the y direction: twice the median |y - <y>|; weighted: the 25-75 % CDF span
+    (analyses.py:99-116)."""
+    fused.flush()
+    y = rays[2]
+    cy = centroid(rays, weights=weights)[1]
+    r = torch.abs(y - cy)
+    if weights is not None:
+        w = _weights(weights, r.shape[0], r.device)
+        r, ind = torch.sort(r, stable=True)
+        cdf = torch.cumsum(w[ind], 0)
+        cdf = cdf / cdf.max()
+        return float(r[torch.argmin(torch.abs(cdf - .75))] - r[torch.argmin(torch.abs(cdf - .25))])
+    n = r.shape[0]
+    if n == 0:
+        return float("nan")
+    lo, hi = _kth(r, [(n - 1) // 2, n // 2])
+    return (lo + hi) * .5 * 2.
+
+
+def radialGrad(x, y, hubscale, yaw, hubdist):
+    """x and y derivatives of a radial-grating phase function; hubscale = lambda / (nn/mm)
+    (analyses.py:403-428, including its quirk: the yaw-rotated y2 is overwritten by y + hubdist).
+    Works on torch tensors (device) or NumPy arrays."""
+    xp = torch if isinstance(x, torch.Tensor) else np
+    x2 = x * math.cos(yaw) + y * math.sin(yaw)
+    y2 = y + hubdist
+    rho_ = xp.sqrt(x2 ** 2 + y2 ** 2)
+    theta = (torch.atan2(-x2, y2) if xp is torch else np.arctan2(-x2, y2))
+    gx = hubscale * (xp.cos(theta) / rho_)
+    gy = -hubscale * (xp.sin(theta) / rho_)
+    return gx, gy
+
+
+def sellmeier(wave, B, C):
+    """Refractive index from Sellmeier coefficients (analyses.py:430-446); host NumPy."""
+    wave = np.reshape(np.asarray(wave, dtype=float), [np.size(wave), 1])
+    B = np.reshape(np.asarray(B, dtype=float), [1, np.size(B)])
+    C = np.reshape(np.asarray(C, dtype=float), [1, np.size(C)])
+    num = np.dot(wave ** 2, B)
+    den = wave ** 2 - C
+    return np.sqrt(1 + np.sum(num / den, axis=1))
+
+
 def analyticImagePlane(rays, weights=None, group=None):
     """Best-focus shift by the analytic method of Ron Elsner's paper (analyses.py:118-133)."""
     s = _moments(rays, weights, group=group)

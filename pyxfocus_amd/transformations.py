@@ -298,6 +298,11 @@ def _m16(mat):
     return a, a.ctypes.data_as(_lib._DP)
 
 
+def skew(vec):
+    """Skew-symmetric cross-product matrix of a 3-vector (transformations.py:291-292)."""
+    return np.array([[0, -vec[2], vec[1]], [vec[2], 0, -vec[0]], [-vec[1], vec[0], 0]])
+
+
 def applyT(rays, coords, inverse=False):
     """Apply transformation matrix to raylist; only rotations to direction cosines and normals.
     inverse=True goes back to the global system.  Returns a NEW list sharing rays[0]

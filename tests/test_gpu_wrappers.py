@@ -748,3 +748,21 @@ def test_wavefront_large_grid_paths():
     got, sweeps = native.reconstruct(ga, gb, 1e-9, bs, gph, 300, return_sweeps=True)
     assert sweeps == port.reconstruct.reconstruct.sweeps
     assert bits_equal(got.cpu().numpy(), want).all() and bits_equal(gph.cpu().numpy(), ph).all()
+
+
+def test_hpdY_matches_numpy():
+    import pyxfocus_amd.analyses as anal
+    rng = np.random.default_rng(8)
+    for n in (1001, 4000):
+        cols = [dev(rng.normal(0., 1. + k, n)) for k in range(10)]
+        y = cols[2].cpu().numpy()
+        want = np.median(np.abs(y - np.average(y))) * 2.
+        assert abs(anal.hpdY(cols) - want) < 1e-14
+        w = rng.uniform(.5, 2., n)
+        cy = np.average(y, weights=w)
+        r = np.abs(y - cy)
+        ind = np.argsort(r, kind="stable")
+        cdf = np.cumsum(w[ind])
+        cdf = cdf / cdf.max()
+        want = r[ind][np.argmin(np.abs(cdf - .75))] - r[ind][np.argmin(np.abs(cdf - .25))]
+        assert abs(anal.hpdY(cols, weights=w) - want) < 1e-12

@@ -191,3 +191,50 @@ def test_program_planner_liveness():
     from pyxfocus_amd import _lib
     with _pt.raises(_lib.PxfError):
         f.plan([mk(99)])
+
+
+def test_design_helpers_match_reference_conicsolve(golden):
+    """conicsolve.py design helpers (host scalar math) against values captured from the reference's
+    own conicsolve.py; transformations.skew against its transformations.py."""
+    import io
+    from contextlib import redirect_stdout
+    from pyxfocus_amd import conicsolve as con
+    g = golden["design"]
+    z = np.linspace(8400., 8500., 7)
+    for tag in "abc":
+        r0, z0, psi = g[tag + "/par"]
+        S = 50000.
+        P, a, b, e, f = con.ellipsoidFunction(S, psi, r0, z0)
+        got = {"primrad": con.primrad(z, r0, z0, psi), "secrad": con.secrad(z - 200., r0, z0, psi),
+               "woltparam": np.array(con.woltparam(r0, z0)), "primfocus": con.primfocus(r0, z0),
+               "primsag": con.primsag(z0 + 100., r0, z0), "secsag": con.secsag(z0 - 100., z0 - 5., r0, z0, psi),
+               "rGoal_to_rMax": con.rGoal_to_rMax(r0 + 1., z0, z0 + 100.),
+               "wsRMS": con.wsRMS(psi, 1e-3, 6.5e-3, 100., z0),
+               "wsFoc": con.wsFoc(np.array([0., 1., 5.]), psi, 100., z0, 6.5e-3),
+               "ellipsoidFunction": np.array([P, a, b, e, f]), "ellipsoidRad": con.ellipsoidRad(S, psi, r0, z0, z),
+               "ehSecRad": con.ehSecRad(S, psi, r0, z0, z - 200.),
+               "ellipsoidSag": con.ellipsoidSag(S, psi, r0, z0, z0 + 100., z0),
+               "solveS": np.array(con.solveS(P, a, b, e, f, r0 + .3, .2, z0 + 50., 1e-3, -2e-3, -np.sqrt(1 - 5e-6)))}
+        for k, v in got.items():
+            assert np.array_equal(np.asarray(v), g["%s/%s" % (tag, k)]), (tag, k)
+    with redirect_stdout(io.StringIO()):
+        radii = con.primaryintercept(221., 219., 8400., 8400., 8500.)
+    assert len(radii) >= 2 and radii[-1] <= 219. < radii[-2] and all(np.diff(radii) < 0)
+    import pyxfocus_amd.transformations as tran
+    assert np.array_equal(tran.skew(np.array([1., -2., 3.5])), g["skew"])
+
+
+def test_sellmeier_and_radialgrad_formulas():
+    """analyses.sellmeier / radialGrad restate closed formulas (analyses.py:403-446; the module itself
+    cannot be imported here: astropy/utilities are absent) -- checked against the formulas directly
+    and a known index: N-BK7 at 587.6 nm is 1.5168."""
+    import pyxfocus_amd.analyses as anal
+    B = [1.03961212, 0.231792344, 1.01046945]
+    Cc = [0.00600069867, 0.0200179144, 103.560653]
+    n = anal.sellmeier(np.array([0.5876, 0.4861]), B, Cc)
+    assert abs(n[0] - 1.5168) < 1e-4 and n[1] > n[0]
+    x, y = np.array([1., -2., .5]), np.array([10., 20., -5.])
+    gx, gy = anal.radialGrad(x, y, 1.5e-5, 0.01, 8000.)
+    x2, y2 = x * np.cos(.01) + y * np.sin(.01), y + 8000.
+    th, rr = np.arctan2(-x2, y2), np.sqrt(x2 ** 2 + y2 ** 2)
+    assert np.array_equal(gx, 1.5e-5 * (np.cos(th) / rr)) and np.array_equal(gy, -1.5e-5 * (np.sin(th) / rr))
