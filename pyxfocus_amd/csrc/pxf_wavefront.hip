@@ -8,9 +8,10 @@
 //
 // All grids are Fortran-ordered like the reference's arrays: a(xi,yi) = a[xi + xdim*yi].
 //
-// southwellbin: bins are private per workgroup in LDS (ds_add_f64 / ds_add_u32) while the grid fits
-// (<= kSwbLdsBins bins), flushed with one global atomic per touched bin; larger grids go straight to
-// global_atomic_add_f64.  The per-bin sums are therefore order-nondeterministic (the reference's own
+// southwellbin: bins are private per workgroup in LDS (ds_add_f64 / ds_add_u32), flushed with one
+// global atomic per touched bin; grids larger than one LDS tile (8000 bins) are done tile by tile,
+// one pass over the rays' x, y per tile (device-scope fp64 atomics straight to memory measured 11x
+// slower than that).  The per-bin sums are order-nondeterministic (the reference's own
 // OpenMP loop is a data race on the same sums): parity of the means is to ~1e-15 relative x
 // sqrt(rays per bin), asserted at 1e-12 in the tests.  Rays outside the grid, which index out of
 // bounds in the reference, are dropped.
@@ -30,7 +31,8 @@
 
 namespace pxf {
 
-constexpr int kSwbLdsBins = 3072;  // 3072 x (8+8+4) B = 60 KB of LDS per workgroup
+constexpr int kSwbTileSmall = 4096;  // x (8+8+4) B = 80 KB : two 512-thread workgroups per CU
+constexpr int kSwbTileLarge = 8000;  // 160 KB of LDS: one 1024-thread workgroup per CU
 constexpr int kSwbBlock = 256;
 
 __device__ __forceinline__ bool swb_bin(double v, double binsize, int dim, int &b)
@@ -44,51 +46,43 @@ __device__ __forceinline__ bool swb_bin(double v, double binsize, int dim, int &
     return true;
 }
 
-template <bool LDSH>
-__global__ __launch_bounds__(kSwbBlock) void swb_accum_kernel(const double *__restrict__ x, const double *__restrict__ y,
-                                                             const double *__restrict__ l, const double *__restrict__ m,
-                                                             int64_t num, double binsize, double *__restrict__ xang,
-                                                             double *__restrict__ yang, unsigned *__restrict__ accum,
-                                                             int xdim, int ydim)
+// Bins [tile0, tile0+tilen) are private to the workgroup in LDS (dynamic: tilen x (8+8+4) B); rays
+// that fall into other tiles are skipped (their l, m are not even read).  One launch per tile.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void swb_accum_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                         const double *__restrict__ l, const double *__restrict__ m,
+                                                         int64_t num, double binsize, double *__restrict__ xang,
+                                                         double *__restrict__ yang, unsigned *__restrict__ accum,
+                                                         int xdim, int ydim, int tile0, int tilen)
 {
-    __shared__ double s_l[LDSH ? kSwbLdsBins : 1];
-    __shared__ double s_m[LDSH ? kSwbLdsBins : 1];
-    __shared__ unsigned s_c[LDSH ? kSwbLdsBins : 1];
-    const int nb = xdim * ydim;
-    if (LDSH) {
-        for (int i = threadIdx.x; i < nb; i += kSwbBlock) {
-            s_l[i] = 0.;
-            s_m[i] = 0.;
-            s_c[i] = 0u;
-        }
-        __syncthreads();
+    extern __shared__ double s_swb[];
+    double *s_l = s_swb, *s_m = s_swb + tilen;
+    unsigned *s_c = reinterpret_cast<unsigned *>(s_swb + 2 * tilen);
+    for (int i = threadIdx.x; i < tilen; i += BLOCK) {
+        s_l[i] = 0.;
+        s_m[i] = 0.;
+        s_c[i] = 0u;
     }
-    const int64_t stride = (int64_t)gridDim.x * kSwbBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kSwbBlock + threadIdx.x; i < num; i += stride) {
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < num; i += stride) {
         const double xv = __builtin_nontemporal_load(x + i), yv = __builtin_nontemporal_load(y + i);
-        const double lv = __builtin_nontemporal_load(l + i), mv = __builtin_nontemporal_load(m + i);
         int xb, yb;
         if (!swb_bin(xv, binsize, xdim, xb) || !swb_bin(yv, binsize, ydim, yb)) continue;
-        const int o = xb + xdim * yb;
-        if (LDSH) {
-            unsafeAtomicAdd(&s_l[o], lv);
-            unsafeAtomicAdd(&s_m[o], mv);
-            atomicAdd(&s_c[o], 1u);
-        } else {
-            unsafeAtomicAdd(&xang[o], lv);
-            unsafeAtomicAdd(&yang[o], mv);
-            atomicAdd(&accum[o], 1u);
-        }
+        const int o = xb + xdim * yb - tile0;
+        if (o < 0 || o >= tilen) continue;
+        const double lv = __builtin_nontemporal_load(l + i), mv = __builtin_nontemporal_load(m + i);
+        unsafeAtomicAdd(&s_l[o], lv);
+        unsafeAtomicAdd(&s_m[o], mv);
+        atomicAdd(&s_c[o], 1u);
     }
-    if (LDSH) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += kSwbBlock) {
-            const unsigned c = s_c[i];
-            if (c) {
-                unsafeAtomicAdd(&xang[i], s_l[i]);
-                unsafeAtomicAdd(&yang[i], s_m[i]);
-                atomicAdd(&accum[i], c);
-            }
+    __syncthreads();
+    for (int i = threadIdx.x; i < tilen; i += BLOCK) {
+        const unsigned c = s_c[i];
+        if (c) {
+            unsafeAtomicAdd(&xang[tile0 + i], s_l[i]);
+            unsafeAtomicAdd(&yang[tile0 + i], s_m[i]);
+            atomicAdd(&accum[tile0 + i], c);
         }
     }
 }
@@ -227,14 +221,29 @@ int pxf_southwellbin(const double *x, const double *y, const double *l, const do
     if (e == hipSuccess) e = hipMemsetAsync(accum, 0, (size_t)nb * sizeof(unsigned), s);
     if (e != hipSuccess) return hip_fail(e);
     if (num > 0) {
-        const int64_t want = (num + kSwbBlock - 1) / kSwbBlock;
-        const int g = (int)(want < 4096 ? want : 4096);  // bounded flush traffic: 4096 x nb atomics at most
-        if (nb <= kSwbLdsBins)
-            hipLaunchKernelGGL((swb_accum_kernel<true>), dim3(g), dim3(kSwbBlock), 0, s, x, y, l, m, num, binsize, xang,
-                               yang, accum, (int)xdim, (int)ydim);
-        else
-            hipLaunchKernelGGL((swb_accum_kernel<false>), dim3(g), dim3(kSwbBlock), 0, s, x, y, l, m, num, binsize, xang,
-                               yang, accum, (int)xdim, (int)ydim);
+        const int tile = nb <= kSwbTileSmall ? nb : (nb < kSwbTileLarge ? nb : kSwbTileLarge);
+        const bool big = tile > kSwbTileSmall;
+        const int block = big ? 1024 : 512;
+        const size_t lds = (size_t)tile * (2 * sizeof(double) + sizeof(unsigned));
+        if (lds > 48 * 1024) {
+            e = big ? hipFuncSetAttribute(reinterpret_cast<const void *>(&swb_accum_kernel<1024>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                    : hipFuncSetAttribute(reinterpret_cast<const void *>(&swb_accum_kernel<512>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return hip_fail(e);
+        }
+        const int64_t want = (num + block - 1) / block;
+        const int64_t cap = (int64_t)device_cus() * (big ? 1 : 2);  // resident workgroups: bounded flush traffic
+        const int g = (int)(want < cap ? want : cap);
+        for (int t0 = 0; t0 < nb; t0 += tile) {
+            const int tn = nb - t0 < tile ? nb - t0 : tile;
+            if (big)
+                hipLaunchKernelGGL((swb_accum_kernel<1024>), dim3(g), dim3(1024), lds, s, x, y, l, m, num, binsize, xang,
+                                   yang, accum, (int)xdim, (int)ydim, t0, tn);
+            else
+                hipLaunchKernelGGL((swb_accum_kernel<512>), dim3(g), dim3(512), lds, s, x, y, l, m, num, binsize, xang,
+                                   yang, accum, (int)xdim, (int)ydim, t0, tn);
+        }
     }
     hipLaunchKernelGGL(swb_final_kernel, dim3((nb + kSwbBlock - 1) / kSwbBlock), dim3(kSwbBlock), 0, s, xang, yang, phase,
                        accum, nb);

@@ -123,9 +123,9 @@ def main():
         ("centroid+rmsCentroid", normal_beam, lambda r: anal.rmsCentroid(r), 32),
         ("hpd (radix select)", normal_beam, lambda r: anal.hpd(r), None),
         ("indAngle", normal_beam, lambda r: anal.indAngle(r), 56),
-        ("southwellbin 48x48 (LDS bins)", normal_beam,
+        ("southwellbin 48x48 (1 LDS tile)", normal_beam,
          lambda r: native.southwellbin(r[1], r[2], r[4], r[5], 1.0, 48, 48), 32),
-        ("southwellbin 128x128 (global atomics)", normal_beam,
+        ("southwellbin 128x128 (3 LDS tiles)", normal_beam,
          lambda r: native.southwellbin(r[1], r[2], r[4], r[5], 0.4, 128, 128), 32),
     ]
 
