@@ -14,3 +14,4 @@ __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401  (does not load the shared library until first use)
 from ._fused import compile_segments, flush, fused  # noqa: E402,F401
+from ._graph import capture  # noqa: E402,F401

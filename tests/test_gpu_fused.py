@@ -245,3 +245,36 @@ def test_segmented_program_equals_per_segment_loop():
             surf.flat(r)
     with pytest.raises(Exception, match="different operation sequence"):
         pxf.compile_segments(c, per, bad, [(g[0], g[1], g[2]) for g in geo])
+
+
+def test_capture_replays_trace_as_hip_graph():
+    """pyxfocus_amd.capture: eager calls + a fused block captured once, replayed on refilled inputs."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from oracle import cases
+    rng = np.random.default_rng(21)
+    c = cases.annulus_rays(rng, 5000, cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR), 0.)
+    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+
+    def trace():
+        tran.transform(rays, 0, 0, -(cases.Z0 + 2 * cases.LMIR), 0, 0, 0)
+        with pxf.fused():
+            surf.wolterprimary(rays, cases.R0, cases.Z0)
+            tran.reflect(rays)
+            surf.woltersecondary(rays, cases.R0, cases.Z0)
+            tran.reflect(rays)
+        surf.flat(rays)
+
+    trace()
+    want = [r.clone() for r in rays]
+    for k, t in zip(ALLCOLS, rays):
+        t.copy_(torch.from_numpy(c[k]))
+    g = pxf.capture(trace)
+    for rep in range(3):
+        for k, t in zip(ALLCOLS, rays):
+            t.copy_(torch.from_numpy(c[k]))
+        g.replay()
+        torch.cuda.synchronize()
+        for w, r in zip(want, rays):
+            assert bits_equal(r.cpu().numpy(), w.cpu().numpy()).all(), rep
