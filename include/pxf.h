@@ -332,6 +332,17 @@ size_t pxf_select_workspace_bytes(void);
 int pxf_kth_values(const double *v, int64_t num, const int64_t *k, int32_t nk, double *out_dev,
                    void *workspace, pxf_stream_t stream);
 
+/* The same selection step by step, for a bundle SHARDED across GPUs ("hpd median via
+ * histogram all-reduce"): begin (global ranks k[]), then for pass = 0 .. pxf_select_passes()-1:
+ * pxf_select_hist on the local shard, SUM the histogram block (and, after pass 0, the NaN counter:
+ * both uint64, located by pxf_select_state_layout inside the workspace) over all ranks, then
+ * pxf_select_pick.  After the last pick out_dev[j] holds the exact global k[j]-th value on every rank. */
+int32_t pxf_select_passes(void);
+void pxf_select_state_layout(int64_t *hist_offset, int64_t *hist_bytes, int64_t *nan_offset);
+int pxf_select_begin(const int64_t *k, int32_t nk, void *workspace, pxf_stream_t stream);
+int pxf_select_hist(const double *v, int64_t num, int32_t nk, void *workspace, int32_t pass, pxf_stream_t stream);
+int pxf_select_pick(int32_t nk, void *workspace, int32_t pass, double *out_dev, pxf_stream_t stream);
+
 /* ---- wavefront sensing: reconstruct.f95 ---------------------------------------------------------
  * Grids are Fortran-ordered like the reference's arrays: a(xi,yi) = a[xi + xdim*yi] (device memory).
  *

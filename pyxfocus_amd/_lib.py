@@ -87,6 +87,11 @@ _SIGS = {
     "pxf_kth_values": [_P, _i64, C.POINTER(C.c_int64), _i32, _P, _P, _P],
     "pxf_source": [_i32, _PP, _i64, _d, _d, _d, _d, _u64, _u64, _P],
     "pxf_source_ex": [_i32, _PP, _i64, _i64, _DP, _u64, _u64, _P],
+    "pxf_select_passes": [],
+    "pxf_select_state_layout": [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "pxf_select_begin": [C.POINTER(C.c_int64), _i32, _P, _P],
+    "pxf_select_hist": [_P, _i64, _i32, _P, _i32, _P],
+    "pxf_select_pick": [_i32, _P, _i32, _P, _P],
     "pxf_southwellbin_workspace_bytes": [_i32, _i32],
     "pxf_southwellbin": [_P, _P, _P, _P, _i64, _d, _P, _P, _P, _i32, _i32, _P, _P],
     "pxf_reconstruct": [_P, _P, _i32, _i32, _d, _d, _P, _P, _i32, _P, _P],
@@ -98,7 +103,8 @@ _SIGS = {
 }
 _RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,
             "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t,
-            "pxf_select_workspace_bytes": C.c_size_t, "pxf_southwellbin_workspace_bytes": C.c_size_t}
+            "pxf_select_workspace_bytes": C.c_size_t, "pxf_southwellbin_workspace_bytes": C.c_size_t,
+            "pxf_select_passes": C.c_int32, "pxf_select_state_layout": None}
 
 EXPORTS = tuple(_SIGS)
 _lib = None

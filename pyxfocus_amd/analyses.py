@@ -152,32 +152,69 @@ def rhocdf(rays, weights=None, cent=True):
     return r, cdf / cdf.max()
 
 
-def _kth(v, ranks):
-    """Order statistics of a device column by radix select (no sort); returns Python floats."""
+def _kth(v, ranks, group=None):
+    """Order statistics of a device column by radix select (no sort); returns Python floats.
+    With `group` the column is this rank's shard of a distributed column and `ranks` are GLOBAL:
+    per pass the 32 KB digit histogram is all-reduced, every rank picks the same bin, and after six
+    passes all ranks hold the exact global values -- no ray leaves its GPU."""
+    import ctypes as C
     num, dev = native._check_cols((v,), "kth_values")
     h = _lib.lib()
     ws = torch.empty(h.pxf_select_workspace_bytes(), dtype=torch.uint8, device=dev)
     out = torch.empty(len(ranks), dtype=torch.float64, device=dev)
-    import ctypes as C
     kk = (C.c_int64 * len(ranks))(*[int(k) for k in ranks])
+    st = native._stream(dev)
+    if group is None:
+        with torch.cuda.device(dev):
+            rc = h.pxf_kth_values(v.data_ptr(), num, kk, len(ranks), out.data_ptr(), ws.data_ptr(), st)
+        _lib.check(rc, "pxf_kth_values")
+        return out.tolist()
+    import torch.distributed as dist
+    grp = None if group is True else group
+    off = [C.c_int64() for _ in range(3)]
+    h.pxf_select_state_layout(*[C.byref(o) for o in off])
+    hist = ws[off[0].value:off[0].value + off[1].value].view(torch.int64)
+    nan = ws[off[2].value:off[2].value + 8].view(torch.int64)
+    nk = len(ranks)
     with torch.cuda.device(dev):
-        rc = h.pxf_kth_values(v.data_ptr(), num, kk, len(ranks), out.data_ptr(), ws.data_ptr(),
-                              native._stream(dev))
-    _lib.check(rc, "pxf_kth_values")
+        _lib.check(h.pxf_select_begin(kk, nk, ws.data_ptr(), st), "pxf_select_begin")
+        for p in range(h.pxf_select_passes()):
+            _lib.check(h.pxf_select_hist(v.data_ptr(), num, nk, ws.data_ptr(), p, st), "pxf_select_hist")
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=grp)
+            if p == 0:
+                dist.all_reduce(nan, op=dist.ReduceOp.SUM, group=grp)
+            _lib.check(h.pxf_select_pick(nk, ws.data_ptr(), p, out.data_ptr(), st), "pxf_select_pick")
     return out.tolist()
 
 
-def hpd(rays, weights=None, cent=True):
+def hpd(rays, weights=None, cent=True, group=None):
     """HPD: twice the median radius from the centroid; weighted: the 25-75 % CDF span
-    (analyses.py:88-97; like the reference, `cent` is ignored and the centroid is always used)."""
+    (analyses.py:88-97; like the reference, `cent` is ignored and the centroid is always used).
+    group= (unweighted only): the rays are this rank's shard; centroid by all-reduced moments, median
+    by all-reduced radix-select histograms -> the exact HPD of the whole bundle on every rank."""
     if weights is not None:
+        if group is not None:
+            raise NotImplementedError("weighted hpd over a process group: gather with dist.all_gather_focal first")
         r, cdf = rhocdf(rays, weights=weights, cent=True)
         return float(r[torch.argmin(torch.abs(cdf - .75))] - r[torch.argmin(torch.abs(cdf - .25))])
-    r = rho(rays, weights=None, cent=True)
-    n = r.shape[0]
+    if group is None:
+        r = rho(rays, weights=None, cent=True)
+        n = r.shape[0]
+    else:
+        import torch.distributed as dist
+        cx, cy = centroid(rays, group=group)
+        x, y = rays[1:3]
+        num, dev = native._check_cols((x, y), "rho")
+        r = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().pxf_rho(x.data_ptr(), y.data_ptr(), float(cx), float(cy), r.data_ptr(), num,
+                                          native._stream(dev)), "pxf_rho")
+        cnt = torch.tensor([num], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=None if group is True else group)
+        n = int(cnt.item())
     if n == 0:
         return float("nan")
-    lo, hi = _kth(r, [(n - 1) // 2, n // 2])        # np.median: mean of the two middle values
+    lo, hi = _kth(r, [(n - 1) // 2, n // 2], group=group)        # np.median: mean of the two middle values
     return (lo + hi) * .5 * 2.
 
 

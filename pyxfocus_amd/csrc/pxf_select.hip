@@ -13,6 +13,7 @@
 // No host round trip between passes; 6 x 8 B/ray of reads instead of a full sort.  NaN anywhere
 // -> NaN out, as np.median does.
 #include <math.h>
+#include <stddef.h>
 
 #include "pxf_kernel.h"
 
@@ -212,6 +213,56 @@ int pxf_dist3(const double *x, const double *y, const double *z, double px, doub
 }
 
 size_t pxf_select_workspace_bytes(void) { return sizeof(SelState); }
+
+// ---- the same selection, step by step, for order statistics over a bundle that is SHARDED across
+// GPUs: every rank builds the digit histogram of its shard, the histograms (and the NaN count) are
+// summed over ranks by the caller (an all-reduce of 32 KB), every rank picks the same bin.  Six
+// rounds give the exact global k-th value with no ray leaving its GPU.
+int32_t pxf_select_passes(void) { return kSelPasses; }
+
+void pxf_select_state_layout(int64_t *hist_offset, int64_t *hist_bytes, int64_t *nan_offset)
+{
+    if (hist_offset) *hist_offset = (int64_t)offsetof(SelState, hist);
+    if (hist_bytes) *hist_bytes = (int64_t)sizeof(((SelState *)nullptr)->hist);
+    if (nan_offset) *nan_offset = (int64_t)offsetof(SelState, nan_count);
+}
+
+int pxf_select_begin(const int64_t *k, int32_t nk, void *workspace, pxf_stream_t stream)
+{
+    if (!k || nk < 1 || nk > kSelMaxRanks || !workspace) return PXF_EINVAL;
+    for (int s = 0; s < nk; s++)
+        if (k[s] < 0) return PXF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(SelState), s);
+    if (e != hipSuccess) return hip_fail(e);
+    hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(1), 0, s, (SelState *)workspace, (long long)k[0],
+                       (long long)(nk > 1 ? k[1] : k[0]));
+    e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_select_hist(const double *v, int64_t num, int32_t nk, void *workspace, int32_t pass, pxf_stream_t stream)
+{
+    if (num < 0 || (num > 0 && !v) || nk < 1 || nk > kSelMaxRanks || !workspace || pass < 0 || pass >= kSelPasses)
+        return PXF_EINVAL;
+    if (num == 0) return PXF_OK;  // an empty shard contributes nothing
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_capped(num);
+    if (nk == 1) hipLaunchKernelGGL((sel_hist_kernel<1>), dim3(g), dim3(kBlock), 0, s, v, num, (SelState *)workspace, (int)pass);
+    else hipLaunchKernelGGL((sel_hist_kernel<2>), dim3(g), dim3(kBlock), 0, s, v, num, (SelState *)workspace, (int)pass);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_select_pick(int32_t nk, void *workspace, int32_t pass, double *out_dev, pxf_stream_t stream)
+{
+    if (nk < 1 || nk > kSelMaxRanks || !workspace || !out_dev || pass < 0 || pass >= kSelPasses) return PXF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (nk == 1) hipLaunchKernelGGL((sel_pick_kernel<1>), dim3(1), dim3(64), 0, s, (SelState *)workspace, (int)pass, out_dev);
+    else hipLaunchKernelGGL((sel_pick_kernel<2>), dim3(1), dim3(64), 0, s, (SelState *)workspace, (int)pass, out_dev);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
 
 int pxf_kth_values(const double *v, int64_t num, const int64_t *k, int32_t nk, double *out_dev,
                    void *workspace, pxf_stream_t stream)

@@ -1,0 +1,84 @@
+"""Two ranks sharing the one GPU of the test box (gloo carries the collectives; on a multi-GPU node
+the same code runs over RCCL): ray-sharded trace + focal-plane metrics by all-reduce only --
+centroid / rmsCentroid from all-reduced moments, and the exact HPD of the WHOLE bundle from
+all-reduced radix-select histograms, no ray leaving its rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, with_nan, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pyxfocus_amd.analyses as anal
+        import pyxfocus_amd.sources as sources
+        import pyxfocus_amd.surfaces as surf
+        import pyxfocus_amd.transformations as tran
+        from pyxfocus_amd import conicsolve as con
+        from pyxfocus_amd import dist as pdist
+        torch.cuda.set_device(0)
+        r0, z0, L = 220., 8400., 100.
+        lo, hi = pdist.shard_range(n)
+        if n == 7 and rank == 1:
+            lo, hi = n, n                               # an EMPTY shard on rank 1 (rank 0 holds everything)
+        elif n == 7:
+            lo, hi = 0, n
+        rays = sources.annulus(float(con.primrad(z0, r0, z0)), float(con.primrad(z0 + L, r0, z0)), hi - lo,
+                               rng="philox", seed=77, first_index=lo)
+        tran.transform(rays, 0, 0, -(z0 + 2 * L), 0, 0, 0)
+        surf.wolterprimary(rays, r0, z0)
+        tran.reflect(rays)
+        surf.woltersecondary(rays, r0, z0)
+        tran.reflect(rays)
+        tran.transform(rays, 0, 0, 3., 0, 0, 0)          # slightly out of focus: a finite spot
+        surf.flat(rays)
+        if with_nan and rank == 0:
+            rays[1][3] = float("nan")
+        out = (anal.hpd(rays, group=True), anal.rmsCentroid(rays, group=True), anal.centroid(rays, group=True))
+        q.put((rank, lo, hi, out, rays[1].cpu().numpy(), rays[2].cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,with_nan", [(200_001, False), (50_000, False), (7, False), (1000, True)])
+def test_sharded_hpd_by_histogram_allreduce(n, with_nan):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, with_nan, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x = np.concatenate([r[4] for r in res])
+    y = np.concatenate([r[5] for r in res])
+    assert len(x) == n
+    for rank, lo, hi, (hpd, rms, cen), _, _ in res:
+        if with_nan:
+            assert np.isnan(hpd)                         # np.median propagates NaN
+            continue
+        cx, cy = x.mean(), y.mean()
+        assert abs(cen[0] - cx) < 1e-12 and abs(cen[1] - cy) < 1e-12
+        rho = np.sqrt((x - cen[0]) ** 2 + (y - cen[1]) ** 2)    # same centre as the ranks used
+        assert hpd == 2. * np.median(rho), (rank, hpd, 2 * np.median(rho))
+        assert abs(rms - np.sqrt(np.mean((x - cx) ** 2 + (y - cy) ** 2))) < 1e-12 * max(1., rms)
+    assert res[0][3] == res[1][3] or with_nan                   # every rank holds the same numbers
