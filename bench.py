@@ -287,6 +287,13 @@ def main():
 
     # ---- focal plane: global metric via all-reduce, and the all-gather the north-star names ----
     rms = anal.rmsCentroid(last, group=True if dist else None)
+    try:        # exact HPD of the whole (sharded) bundle: radix-select histograms all-reduced, no ray moves
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        hpd = anal.hpd(last, group=True if dist else None)
+        hpd = {"mm": hpd, "ms": (time.perf_counter() - h0) * 1e3}
+    except Exception as e:
+        hpd = {"error": repr(e)[:200]}
     gather = None
     if dist and not args.no_gather:
         try:
@@ -316,7 +323,7 @@ def main():
                           "bundles_pregenerated": pool, "bundles_regenerated_in_timed_region": regen},
                "roofline": roofline,
                "chain_GBps": chain_gbps, "chain_frac_of_hbm_peak": chain_gbps / HBM_PEAK_GBS,
-               "kernels": kern, "focal_rms_centroid_mm": rms, "focal_gather": gather,
+               "kernels": kern, "focal_rms_centroid_mm": rms, "focal_hpd": hpd, "focal_gather": gather,
                "fused": fused}
         if n_gpus == 1 and not args.no_cpu_baseline:
             def gpu_chain(cols, use_fused):
