@@ -343,6 +343,25 @@ int pxf_select_begin(const int64_t *k, int32_t nk, void *workspace, pxf_stream_t
 int pxf_select_hist(const double *v, int64_t num, int32_t nk, void *workspace, int32_t pass, pxf_stream_t stream);
 int pxf_select_pick(int32_t nk, void *workspace, int32_t pass, double *out_dev, pxf_stream_t stream);
 
+/* Weighted quantiles without a sort (analyses.hpd with weights, analyses.py:73-97): out_dev[j] =
+ * r[argmin |cdf - q[j]|] of the reference (cdf = cumsum of the weights in order of increasing v,
+ * normalised), for nq <= 2 quantiles q[] (HOST array, 0 < q <= 1) and positive weights w.  Weighted
+ * radix descent + one neighbour pass: 7 reads of v and 6 of w.  `workspace`:
+ * pxf_wselect_workspace_bytes().  The step-wise entries serve a bundle sharded across GPUs: after
+ * every pxf_wselect_hist SUM the fp64 histogram block over ranks; after pxf_wselect_neighbors take
+ * the MAX of the int64 `prev` pair and the SUM of the uint64 `count` pair (pxf_wselect_state_layout);
+ * then pxf_wselect_finish. */
+size_t pxf_wselect_workspace_bytes(void);
+int pxf_wquantiles(const double *v, const double *w, int64_t num, const double *q, int32_t nq, double *out_dev,
+                   void *workspace, pxf_stream_t stream);
+void pxf_wselect_state_layout(int64_t *hist_offset, int64_t *hist_bytes, int64_t *prev_offset, int64_t *count_offset);
+int pxf_wselect_begin(const double *q, int32_t nq, void *workspace, pxf_stream_t stream);
+int pxf_wselect_hist(const double *v, const double *w, int64_t num, int32_t nq, void *workspace, int32_t pass,
+                     pxf_stream_t stream);
+int pxf_wselect_pick(int32_t nq, void *workspace, int32_t pass, pxf_stream_t stream);
+int pxf_wselect_neighbors(const double *v, int64_t num, int32_t nq, void *workspace, pxf_stream_t stream);
+int pxf_wselect_finish(int32_t nq, void *workspace, double *out_dev, pxf_stream_t stream);
+
 /* ---- wavefront sensing: reconstruct.f95 ---------------------------------------------------------
  * Grids are Fortran-ordered like the reference's arrays: a(xi,yi) = a[xi + xdim*yi] (device memory).
  *

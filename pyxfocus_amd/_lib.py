@@ -92,6 +92,14 @@ _SIGS = {
     "pxf_select_begin": [C.POINTER(C.c_int64), _i32, _P, _P],
     "pxf_select_hist": [_P, _i64, _i32, _P, _i32, _P],
     "pxf_select_pick": [_i32, _P, _i32, _P, _P],
+    "pxf_wselect_workspace_bytes": [],
+    "pxf_wquantiles": [_P, _P, _i64, _DP, _i32, _P, _P, _P],
+    "pxf_wselect_state_layout": [C.POINTER(C.c_int64)] * 4,
+    "pxf_wselect_begin": [_DP, _i32, _P, _P],
+    "pxf_wselect_hist": [_P, _P, _i64, _i32, _P, _i32, _P],
+    "pxf_wselect_pick": [_i32, _P, _i32, _P],
+    "pxf_wselect_neighbors": [_P, _i64, _i32, _P, _P],
+    "pxf_wselect_finish": [_i32, _P, _P, _P],
     "pxf_southwellbin_workspace_bytes": [_i32, _i32],
     "pxf_southwellbin": [_P, _P, _P, _P, _i64, _d, _P, _P, _P, _i32, _i32, _P, _P],
     "pxf_reconstruct": [_P, _P, _i32, _i32, _d, _d, _P, _P, _i32, _P, _P],
@@ -104,7 +112,8 @@ _SIGS = {
 _RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,
             "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t,
             "pxf_select_workspace_bytes": C.c_size_t, "pxf_southwellbin_workspace_bytes": C.c_size_t,
-            "pxf_select_passes": C.c_int32, "pxf_select_state_layout": None}
+            "pxf_select_passes": C.c_int32, "pxf_select_state_layout": None,
+            "pxf_wselect_workspace_bytes": C.c_size_t, "pxf_wselect_state_layout": None}
 
 EXPORTS = tuple(_SIGS)
 _lib = None

@@ -175,6 +175,189 @@ struct IndAngleOp {
     }
 };
 
+
+// ---- weighted quantiles (analyses.hpd with weights, analyses.py:73-97) without a sort ------------
+// The reference sorts the radii, forms cdf = cumsum(w)/sum(w) and takes r[argmin |cdf - q|] for
+// q = .75 and .25.  With positive weights that element is either the first one whose cdf reaches q
+// (index k) or its predecessor (argmin returns the first of two equal distances).  The same MSD
+// radix descent as above finds r_k when the per-digit histograms hold WEIGHT instead of counts
+// (fp64 ds_add / global atomic add): after six passes the state has the key of r_k, the weight B
+// of all keys below it and the weight G at it; one more pass finds the largest key below r_k and
+// the number of elements equal to r_k; a last single-thread kernel makes the reference's choice:
+//   predecessor  if r_k is unique, a predecessor exists and |B/W - q| <= |(B+G)/W - q|,  else r_k
+// (several elements tied at r_k: whichever of them crosses, its predecessor in sorted order has the
+// same value unless it is the first of the tie, which the arbitrary order of an unstable argsort
+// does not define either).  Sums are formed in a different order than np.cumsum: the choice can
+// differ from the reference's only when the two distances agree to ~1e-13 relative.
+struct WSelState {
+    double hist[kSelMaxRanks][kSelBins];
+    unsigned long long prefix[kSelMaxRanks];
+    double below[kSelMaxRanks];   // weight of all keys strictly below the range selected so far
+    double target[kSelMaxRanks];  // q * W
+    double q[kSelMaxRanks];
+    double at[kSelMaxRanks];      // weight at the final key (G)
+    double total;                 // W
+    long long prev[kSelMaxRanks];             // largest key below r_k, as a signed-monotone image
+    unsigned long long count_at[kSelMaxRanks];  // elements equal to r_k
+};
+constexpr long long kNoPrev = (long long)0x8000000000000000ull;
+
+__device__ __forceinline__ long long signed_key(unsigned long long key) { return (long long)(key ^ 0x8000000000000000ull); }
+__device__ __forceinline__ unsigned long long unsigned_key(long long sk) { return (unsigned long long)sk ^ 0x8000000000000000ull; }
+
+template <int NK>
+__global__ __launch_bounds__(kBlock) void wsel_hist_kernel(const double *__restrict__ v, const double *__restrict__ w,
+                                                           int64_t num, WSelState *__restrict__ st, int pass)
+{
+    __shared__ double s_hist[NK][kSelBins];
+    for (int i = threadIdx.x; i < NK * kSelBins; i += kBlock) (&s_hist[0][0])[i] = 0.;
+    __syncthreads();
+    const int shift = sel_shift(pass), width = sel_width(pass);
+    const unsigned dmask = (1u << width) - 1u;
+    unsigned long long prefix[NK];
+#pragma unroll
+    for (int s = 0; s < NK; s++) prefix[s] = st->prefix[s];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+        const unsigned long long key = key_of(v[i]);
+        const unsigned digit = (unsigned)(key >> shift) & dmask;
+        const unsigned long long hi = pass == 0 ? 0ull : (key >> (shift + width));
+        bool any = pass == 0;
+#pragma unroll
+        for (int s = 0; s < NK; s++) any |= hi == prefix[s];
+        if (!any) continue;
+        const double wi = w[i];
+#pragma unroll
+        for (int s = 0; s < NK; s++)
+            if (pass == 0 || hi == prefix[s]) unsafeAtomicAdd(&s_hist[s][digit], wi);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NK * kSelBins; i += kBlock) {
+        const double c = (&s_hist[0][0])[i];
+        if (c != 0.) unsafeAtomicAdd(&st->hist[i / kSelBins][i % kSelBins], c);
+    }
+}
+
+// one wave: W (pass 0), then the bin where the running weight first reaches the target
+template <int NK>
+__global__ __launch_bounds__(64) void wsel_pick_kernel(WSelState *__restrict__ st, int pass)
+{
+    const int lane = threadIdx.x;
+    const int width = sel_width(pass), nb = 1 << width, per = nb / 64;
+    for (int s = 0; s < NK; s++) {
+        double run = 0.;
+        for (int j = 0; j < per; j++) run += st->hist[s][lane * per + j];
+        double incl = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        const double tot = __shfl(incl, 63, 64);
+        if (pass == 0) {
+            if (lane == 0) {
+                if (s == 0) st->total = tot;
+                st->target[s] = st->q[s] * tot;
+            }
+            __syncthreads();
+        }
+        const double target = pass == 0 ? st->q[s] * tot : st->target[s];
+        const double below = st->below[s];
+        const double excl = incl - run;
+        // first lane whose inclusive running weight reaches the target (the last non-empty lane if
+        // rounding leaves the grand total a hair short of it)
+        const bool reach = below + incl >= target;
+        const unsigned long long m = __ballot(reach);
+        const unsigned long long nz = __ballot(run != 0.);
+        int pick = m ? __ffsll((long long)m) - 1 : (nz ? 63 - __clzll((long long)nz) : 0);
+        if (lane == pick) {
+            double cum = below + excl;
+            int b = lane * per, last_nz = -1;
+            double cum_last = cum;
+            for (; b < lane * per + per; b++) {
+                const double c = st->hist[s][b];
+                if (c != 0.) {
+                    last_nz = b;
+                    cum_last = cum;
+                }
+                if (c != 0. && cum + c >= target) break;
+                cum += c;
+            }
+            if (b == lane * per + per) {  // fell off the end (rounding): take the last non-empty bin
+                b = last_nz < 0 ? lane * per : last_nz;
+                cum = cum_last;
+            }
+            st->prefix[s] = (st->prefix[s] << width) | (unsigned long long)b;
+            st->below[s] = cum;
+            st->at[s] = st->hist[s][b];
+        }
+        __syncthreads();
+        for (int j = lane; j < kSelBins; j += 64) st->hist[s][j] = 0.;
+        __syncthreads();
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(kBlock) void wsel_neighbors_kernel(const double *__restrict__ v, int64_t num,
+                                                                WSelState *__restrict__ st)
+{
+    unsigned long long keyk[NK];
+    long long best[NK];
+    unsigned cnt[NK];
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+        keyk[s] = st->prefix[s];
+        best[s] = kNoPrev;
+        cnt[s] = 0u;
+    }
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+        const unsigned long long key = key_of(v[i]);
+#pragma unroll
+        for (int s = 0; s < NK; s++) {
+            if (key == keyk[s]) cnt[s]++;
+            else if (key < keyk[s]) {
+                const long long sk = signed_key(key);
+                best[s] = sk > best[s] ? sk : best[s];
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NK; s++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const long long o = __shfl_down(best[s], off);
+            best[s] = o > best[s] ? o : best[s];
+            cnt[s] += __shfl_down(cnt[s], off);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (best[s] != kNoPrev) atomicMax(&st->prev[s], best[s]);
+            if (cnt[s]) atomicAdd(&st->count_at[s], (unsigned long long)cnt[s]);
+        }
+    }
+}
+
+__global__ void wsel_init_kernel(WSelState *__restrict__ st, double q0, double q1)
+{
+    st->q[0] = q0;
+    st->q[1] = q1;
+    st->prev[0] = kNoPrev;
+    st->prev[1] = kNoPrev;
+}
+
+__global__ void wsel_finish_kernel(const WSelState *__restrict__ st, int nk, double *__restrict__ out)
+{
+    for (int s = 0; s < nk; s++) {
+        const double rk = value_of(st->prefix[s]);
+        double r = rk;
+        if (st->count_at[s] == 1ull && st->prev[s] != kNoPrev) {
+            const double W = st->total, q = st->q[s];
+            const double dprev = fabs(st->below[s] / W - q), dk = fabs((st->below[s] + st->at[s]) / W - q);
+            if (dprev <= dk) r = value_of(unsigned_key(st->prev[s]));
+        }
+        out[s] = r;
+    }
+}
+
 }  // namespace pxf
 
 using namespace pxf;
@@ -287,6 +470,90 @@ int pxf_kth_values(const double *v, int64_t num, const int64_t *k, int32_t nk, d
     }
     e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+// ---- weighted quantiles ---------------------------------------------------------------------------
+size_t pxf_wselect_workspace_bytes(void) { return sizeof(WSelState); }
+
+void pxf_wselect_state_layout(int64_t *hist_offset, int64_t *hist_bytes, int64_t *prev_offset, int64_t *count_offset)
+{
+    if (hist_offset) *hist_offset = (int64_t)offsetof(WSelState, hist);
+    if (hist_bytes) *hist_bytes = (int64_t)sizeof(((WSelState *)nullptr)->hist);
+    if (prev_offset) *prev_offset = (int64_t)offsetof(WSelState, prev);
+    if (count_offset) *count_offset = (int64_t)offsetof(WSelState, count_at);
+}
+
+int pxf_wselect_begin(const double *q, int32_t nq, void *workspace, pxf_stream_t stream)
+{
+    if (!q || nq < 1 || nq > kSelMaxRanks || !workspace) return PXF_EINVAL;
+    for (int s = 0; s < nq; s++)
+        if (!(q[s] > 0. && q[s] <= 1.)) return PXF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(WSelState), s);
+    if (e != hipSuccess) return hip_fail(e);
+    hipLaunchKernelGGL(wsel_init_kernel, dim3(1), dim3(1), 0, s, (WSelState *)workspace, q[0], nq > 1 ? q[1] : q[0]);
+    e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_wselect_hist(const double *v, const double *w, int64_t num, int32_t nq, void *workspace, int32_t pass,
+                     pxf_stream_t stream)
+{
+    if (num < 0 || (num > 0 && (!v || !w)) || nq < 1 || nq > kSelMaxRanks || !workspace || pass < 0 ||
+        pass >= kSelPasses)
+        return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_capped(num);
+    if (nq == 1) hipLaunchKernelGGL((wsel_hist_kernel<1>), dim3(g), dim3(kBlock), 0, s, v, w, num, (WSelState *)workspace, (int)pass);
+    else hipLaunchKernelGGL((wsel_hist_kernel<2>), dim3(g), dim3(kBlock), 0, s, v, w, num, (WSelState *)workspace, (int)pass);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_wselect_pick(int32_t nq, void *workspace, int32_t pass, pxf_stream_t stream)
+{
+    if (nq < 1 || nq > kSelMaxRanks || !workspace || pass < 0 || pass >= kSelPasses) return PXF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (nq == 1) hipLaunchKernelGGL((wsel_pick_kernel<1>), dim3(1), dim3(64), 0, s, (WSelState *)workspace, (int)pass);
+    else hipLaunchKernelGGL((wsel_pick_kernel<2>), dim3(1), dim3(64), 0, s, (WSelState *)workspace, (int)pass);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_wselect_neighbors(const double *v, int64_t num, int32_t nq, void *workspace, pxf_stream_t stream)
+{
+    if (num < 0 || (num > 0 && !v) || nq < 1 || nq > kSelMaxRanks || !workspace) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int g = grid_capped(num);
+    if (nq == 1) hipLaunchKernelGGL((wsel_neighbors_kernel<1>), dim3(g), dim3(kBlock), 0, s, v, num, (WSelState *)workspace);
+    else hipLaunchKernelGGL((wsel_neighbors_kernel<2>), dim3(g), dim3(kBlock), 0, s, v, num, (WSelState *)workspace);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_wselect_finish(int32_t nq, void *workspace, double *out_dev, pxf_stream_t stream)
+{
+    if (nq < 1 || nq > kSelMaxRanks || !workspace || !out_dev) return PXF_EINVAL;
+    hipLaunchKernelGGL(wsel_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const WSelState *)workspace, (int)nq,
+                       out_dev);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_wquantiles(const double *v, const double *w, int64_t num, const double *q, int32_t nq, double *out_dev,
+                   void *workspace, pxf_stream_t stream)
+{
+    if (num <= 0) return PXF_EINVAL;
+    int rc = pxf_wselect_begin(q, nq, workspace, stream);
+    for (int p = 0; rc == PXF_OK && p < kSelPasses; p++) {
+        rc = pxf_wselect_hist(v, w, num, nq, workspace, p, stream);
+        if (rc == PXF_OK) rc = pxf_wselect_pick(nq, workspace, p, stream);
+    }
+    if (rc == PXF_OK) rc = pxf_wselect_neighbors(v, num, nq, workspace, stream);
+    if (rc == PXF_OK) rc = pxf_wselect_finish(nq, workspace, out_dev, stream);
+    return rc;
 }
 
 }  // extern "C"

@@ -50,7 +50,10 @@ def _worker(rank, world, port, n, with_nan, q):
         if with_nan and rank == 0:
             rays[1][3] = float("nan")
         out = (anal.hpd(rays, group=True), anal.rmsCentroid(rays, group=True), anal.centroid(rays, group=True))
-        q.put((rank, lo, hi, out, rays[1].cpu().numpy(), rays[2].cpu().numpy()))
+        # weights keyed on the GLOBAL ray index, so the sharded run weighs exactly the single bundle
+        w = 1. + .5 * torch.sin(torch.arange(lo, hi, dtype=torch.float64, device="cuda") * .37)
+        whpd = float("nan") if with_nan else anal.hpd(rays, weights=w, group=True)
+        q.put((rank, lo, hi, out + (whpd,), rays[1].cpu().numpy(), rays[2].cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -72,7 +75,7 @@ def test_sharded_hpd_by_histogram_allreduce(n, with_nan):
     x = np.concatenate([r[4] for r in res])
     y = np.concatenate([r[5] for r in res])
     assert len(x) == n
-    for rank, lo, hi, (hpd, rms, cen), _, _ in res:
+    for rank, lo, hi, (hpd, rms, cen, whpd), _, _ in res:
         if with_nan:
             assert np.isnan(hpd)                         # np.median propagates NaN
             continue
@@ -81,4 +84,13 @@ def test_sharded_hpd_by_histogram_allreduce(n, with_nan):
         rho = np.sqrt((x - cen[0]) ** 2 + (y - cen[1]) ** 2)    # same centre as the ranks used
         assert hpd == 2. * np.median(rho), (rank, hpd, 2 * np.median(rho))
         assert abs(rms - np.sqrt(np.mean((x - cx) ** 2 + (y - cy) ** 2))) < 1e-12 * max(1., rms)
+        # weighted HPD of the whole bundle (analyses.py:73-97) from all-reduced weight histograms
+        w = 1. + .5 * np.sin(np.arange(n) * .37)
+        wx, wy = np.average(x, weights=w), np.average(y, weights=w)
+        rw = np.sqrt((x - wx) ** 2 + (y - wy) ** 2)
+        ind = np.argsort(rw, kind="stable")
+        cdf = np.cumsum(w[ind])
+        cdf = cdf / cdf.max()
+        want = rw[ind][np.argmin(np.abs(cdf - .75))] - rw[ind][np.argmin(np.abs(cdf - .25))]
+        assert abs(whpd - want) <= 1e-9 * want + 1e-300, (rank, whpd, want)
     assert res[0][3] == res[1][3] or with_nan                   # every rank holds the same numbers

@@ -766,3 +766,45 @@ def test_hpdY_matches_numpy():
         cdf = cdf / cdf.max()
         want = r[ind][np.argmin(np.abs(cdf - .75))] - r[ind][np.argmin(np.abs(cdf - .25))]
         assert abs(anal.hpdY(cols, weights=w) - want) < 1e-12
+
+
+def _ref_whpd(r, w):
+    """The reference's weighted HPD on given radii (analyses.py:73-97)."""
+    ind = np.argsort(r, kind="stable")
+    rs, cdf = r[ind], np.cumsum(w[ind])
+    cdf = cdf / cdf.max()
+    return rs[np.argmin(np.abs(cdf - .75))] - rs[np.argmin(np.abs(cdf - .25))]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 65537, 1_000_003])
+def test_weighted_hpd_by_weighted_radix_select(n):
+    """Weighted HPD without a sort: equals the reference's argsort/cumsum/argmin construction on the
+    same radii -- uniform, random and heavy-tailed weights, radii spanning many binades, and ties."""
+    import pyxfocus_amd.analyses as anal
+    rng = np.random.default_rng(n)
+    for trial in range(3):
+        x = rng.normal(0, 1., n) * np.exp(rng.normal(0, 2., n))
+        y = rng.normal(0, 1., n)
+        if trial == 2 and n > 3:                        # ties: many identical positions
+            x[: n // 2] = x[0]
+            y[: n // 2] = y[0]
+        w = {0: np.ones(n), 1: rng.uniform(.1, 3., n), 2: rng.pareto(1.5, n) + 1e-3}[trial]
+        rays = [dev(np.zeros(n)), dev(x), dev(y)] + [dev(np.zeros(n)) for _ in range(7)]
+        cx, cy = anal.centroid(rays, weights=w)
+        r = np.sqrt((x - cx) ** 2 + (y - cy) ** 2)
+        got = anal.hpd(rays, weights=w)
+        want = _ref_whpd(r, w)
+        if trial == 2 and n > 3:
+            # inside a run of equal radii the order of the reference's sort is arbitrary; what is
+            # defined: each quantile is the tied group where the cdf crosses q, or its predecessor
+            vals = anal._wquantiles(dev(r), dev(w), (.75, .25))
+            uniq = np.unique(r)
+            for v, q in zip(vals, (.75, .25)):
+                assert v in uniq
+                below, upto = w[r < v].sum() / w.sum(), w[r <= v].sum() / w.sum()
+                nxt = uniq[np.searchsorted(uniq, v) + 1] if v < uniq[-1] else None
+                crossing = below < q <= upto + 1e-12
+                pred = nxt is not None and upto < q + 1e-12 and w[r <= nxt].sum() / w.sum() >= q - 1e-12
+                assert crossing or pred, (n, q, v, below, upto)
+            continue
+        assert got == want, (n, trial, got, want)

@@ -122,6 +122,7 @@ def main():
         ("vignette(all kept)", normal_beam, lambda r: tran.vignette(r), 168),
         ("centroid+rmsCentroid", normal_beam, lambda r: anal.rmsCentroid(r), 32),
         ("hpd (radix select)", normal_beam, lambda r: anal.hpd(r), None),
+        ("hpd weighted (weighted radix select)", normal_beam, lambda r: anal.hpd(r, weights=r[9]), None),
         ("indAngle", normal_beam, lambda r: anal.indAngle(r), 56),
         ("southwellbin 48x48 (1 LDS tile)", normal_beam,
          lambda r: native.southwellbin(r[1], r[2], r[4], r[5], 1.0, 48, 48), 32),
