@@ -36,7 +36,8 @@ def rows(pattern):
     f = glob.glob(os.path.join(src, pattern))
     if not f:
         return []
-    with open(f[0]) as fh:
+    f.sort(key=os.path.getmtime)          # gpurun merges into an existing directory: newest run wins
+    with open(f[-1]) as fh:
         return list(csv.DictReader(fh))
 
 

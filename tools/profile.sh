@@ -6,7 +6,7 @@ set -o pipefail
 TAG=${1:-r01}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="${@:---steps 5 --warmup 1 --no-cpu-baseline}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || { echo "trace failed"; tail -5 "$OUT/trace.err"; exit 1; }
