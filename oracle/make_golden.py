@@ -269,6 +269,20 @@ def main():
         blob[tag + "/solveS"] = np.array(con.solveS(P, a, b, e, f, r0 + .3, .2, z0 + 50., 1e-3, -2e-3,
                                                     -np.sqrt(1 - 5e-6)))
     blob["skew"] = tran.skew(np.array([1., -2., 3.5]))
+    # the reference's own southwell.py over the compiled reconstruct.f95 (its `import reconstruct`
+    # resolved to the f2py-style adapter of oracle/api.py); data of its example(), 60 x 60
+    rec = types.ModuleType("reconstruct")
+    rec.reconstruct = ref.reconstruct.reconstruct
+    sys.modules["reconstruct"] = rec
+    sw = _load_by_path("refsouthwell", os.path.join(REF, "southwell.py"))
+    xg, yg = np.meshgrid(np.linspace(-1, 1, 60), np.linspace(-1, 1, 60))
+    img = np.polynomial.legendre.legval2d(xg, yg, [[0, 1, 0], [0, .5, 0], [1, 0, 0]])
+    gx, gy = np.gradient(img)
+    rad = np.sqrt(xg ** 2 + yg ** 2)
+    gx[rad > 1] = np.nan
+    gy[rad > 1] = np.nan
+    blob["southwell/gx"], blob["southwell/gy"] = gx.copy(), gy.copy()
+    blob["southwell/out"] = sw.southwell(gx, gy, 1e-12, 1.)
     np.savez_compressed(os.path.join(OUT, "design.npz"), **blob)
     print("design:", len(blob), "arrays")
 

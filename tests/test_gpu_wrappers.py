@@ -808,3 +808,16 @@ def test_weighted_hpd_by_weighted_radix_select(n):
                 assert crossing or pred, (n, q, v, below, upto)
             continue
         assert got == want, (n, trial, got, want)
+
+
+def test_southwell_module_matches_reference_southwell_py(golden):
+    """pyxfocus_amd.southwell.southwell == the reference's southwell.py over its compiled
+    reconstruct.f95 (golden from oracle/make_golden.py): NaN handling, padding, sign, bit for bit."""
+    from pyxfocus_amd import southwell as sw
+    g = golden["design"]
+    gx, gy = g["southwell/gx"].copy(), g["southwell/gy"].copy()
+    out = sw.southwell(gx, gy, 1e-12, 1.).cpu().numpy()
+    want = g["southwell/out"]
+    assert out.shape == want.shape and np.array_equal(np.isnan(out), np.isnan(want))
+    assert bits_equal(out, want).all()
+    assert (gx[np.isnan(want)] == 100.).all()                 # in-place sentinel, as in the reference
