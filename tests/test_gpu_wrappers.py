@@ -675,7 +675,7 @@ def test_device_grid_and_extended_sources(golden):
                 assert bits_equal(r, w).all(), (tag, k)
             else:
                 assert np.abs(r - w).max() < 1e-15, (tag, k)
-    # a big grid, sharded: two halves == the whole
+    # a big grid (10^6 points): end points exact
     full = sources.rectArray(3., 4., 1000, on_device=True)
     assert full[1].shape[0] == 10 ** 6 and float(full[1].max()) == 3. and float(full[2].min()) == -4.
     n = 400_000
