@@ -343,6 +343,19 @@ int pxf_select_begin(const int64_t *k, int32_t nk, void *workspace, pxf_stream_t
 int pxf_select_hist(const double *v, int64_t num, int32_t nk, void *workspace, int32_t pass, pxf_stream_t stream);
 int pxf_select_pick(int32_t nk, void *workspace, int32_t pass, double *out_dev, pxf_stream_t stream);
 
+/* Order statistics of the RADII rho_i = sqrt((x_i-cx)^2+(y_i-cy)^2) (mode 0) or |y_i-cy| (mode 1)
+ * straight from x, y in one pass over the rays (analyses.hpd / hpdY = twice their median): a strided
+ * sample brackets the wanted ranks, one pass counts the radii below the bracket and collects those
+ * inside it, the exact k[j]-th values are selected among the collected ones.  *ok_dev = 1 when the
+ * bracket held (then out_dev[j] is exactly the k[j]-th smallest radius; NaN if any radius is NaN),
+ * 0 when it did not (many tied radii, or two ranks far apart: ONE bracket spans both): fall back to
+ * pxf_rho + pxf_kth_values.  16 B/ray instead of 72.
+ * `workspace`: pxf_radial_kth_workspace_bytes(num) bytes of device memory. */
+size_t pxf_radial_kth_workspace_bytes(int64_t num);
+int pxf_radial_kth(const double *x, const double *y, double cx, double cy, int32_t mode, int64_t num,
+                   const int64_t *k, int32_t nk, double *out_dev, int32_t *ok_dev, void *workspace,
+                   pxf_stream_t stream);
+
 /* Weighted quantiles without a sort (analyses.hpd with weights, analyses.py:73-97): out_dev[j] =
  * r[argmin |cdf - q[j]|] of the reference (cdf = cumsum of the weights in order of increasing v,
  * normalised), for nq <= 2 quantiles q[] (HOST array, 0 < q <= 1) and positive weights w.  Weighted

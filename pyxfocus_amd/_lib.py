@@ -92,6 +92,8 @@ _SIGS = {
     "pxf_select_begin": [C.POINTER(C.c_int64), _i32, _P, _P],
     "pxf_select_hist": [_P, _i64, _i32, _P, _i32, _P],
     "pxf_select_pick": [_i32, _P, _i32, _P, _P],
+    "pxf_radial_kth_workspace_bytes": [_i64],
+    "pxf_radial_kth": [_P, _P, _d, _d, _i32, _i64, C.POINTER(C.c_int64), _i32, _P, _P, _P, _P],
     "pxf_wselect_workspace_bytes": [],
     "pxf_wquantiles": [_P, _P, _i64, _DP, _i32, _P, _P, _P],
     "pxf_wselect_state_layout": [C.POINTER(C.c_int64)] * 4,
@@ -113,7 +115,7 @@ _RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,
             "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t,
             "pxf_select_workspace_bytes": C.c_size_t, "pxf_southwellbin_workspace_bytes": C.c_size_t,
             "pxf_select_passes": C.c_int32, "pxf_select_state_layout": None,
-            "pxf_wselect_workspace_bytes": C.c_size_t, "pxf_wselect_state_layout": None}
+            "pxf_wselect_workspace_bytes": C.c_size_t, "pxf_radial_kth_workspace_bytes": C.c_size_t, "pxf_wselect_state_layout": None}
 
 EXPORTS = tuple(_SIGS)
 _lib = None

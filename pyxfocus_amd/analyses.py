@@ -225,6 +225,27 @@ def _wquantiles(v, w, qs, group=None):
     return out.tolist()
 
 
+_FAST_MEDIAN_MIN = 1 << 22      # below this the six-pass select is already launch-bound
+
+
+def _radial_kth(rays, cx, cy, ranks, mode=0):
+    """Order statistics of the radii about (cx, cy) (mode 1: of |y - cy|) in ONE pass over x, y
+    (pxf_radial_kth: sample bracket + candidate select); None when the bracket did not hold."""
+    import ctypes as C
+    x, y = rays[1:3]
+    num, dev = native._check_cols((x, y), "radial_kth")
+    h = _lib.lib()
+    ws = torch.empty(h.pxf_radial_kth_workspace_bytes(num), dtype=torch.uint8, device=dev)
+    out = torch.empty(len(ranks), dtype=torch.float64, device=dev)
+    ok = torch.zeros(1, dtype=torch.int32, device=dev)
+    kk = (C.c_int64 * len(ranks))(*[int(k) for k in ranks])
+    with torch.cuda.device(dev):
+        rc = h.pxf_radial_kth(x.data_ptr(), y.data_ptr(), float(cx), float(cy), mode, num, kk, len(ranks),
+                              out.data_ptr(), ok.data_ptr(), ws.data_ptr(), native._stream(dev))
+    _lib.check(rc, "pxf_radial_kth")
+    return out.tolist() if int(ok.item()) == 1 else None
+
+
 def _rho_about(rays, cx, cy):
     x, y = rays[1:3]
     num, dev = native._check_cols((x, y), "rho")
@@ -249,8 +270,13 @@ def hpd(rays, weights=None, cent=True, group=None):
         hi, lo = _wquantiles(r, w, (.75, .25), group=group)
         return hi - lo
     if group is None:
+        n = rays[1].shape[0]
+        if n >= _FAST_MEDIAN_MIN:
+            cx, cy = centroid(rays)
+            got = _radial_kth(rays, cx, cy, [(n - 1) // 2, n // 2])
+            if got is not None:
+                return (got[0] + got[1]) * .5 * 2.
         r = rho(rays, weights=None, cent=True)
-        n = r.shape[0]
     else:
         import torch.distributed as dist
         cx, cy = centroid(rays, group=group)
@@ -270,14 +296,18 @@ def hpdY(rays, weights=None):
     fused.flush()
     y = rays[2]
     cy = centroid(rays, weights=weights)[1]
-    r = torch.abs(y - cy)
+    n = y.shape[0]
     if weights is not None:
-        hi, lo = _wquantiles(r, _weights(weights, r.shape[0], r.device), (.75, .25))
+        r = torch.abs(y - cy)
+        hi, lo = _wquantiles(r, _weights(weights, n, r.device), (.75, .25))
         return hi - lo
-    n = r.shape[0]
     if n == 0:
         return float("nan")
-    lo, hi = _kth(r, [(n - 1) // 2, n // 2])
+    if n >= _FAST_MEDIAN_MIN:
+        got = _radial_kth(rays, 0., cy, [(n - 1) // 2, n // 2], mode=1)
+        if got is not None:
+            return (got[0] + got[1]) * .5 * 2.
+    lo, hi = _kth(torch.abs(y - cy), [(n - 1) // 2, n // 2])
     return (lo + hi) * .5 * 2.
 
 

@@ -46,8 +46,13 @@ __device__ __forceinline__ double value_of(unsigned long long key)
 
 template <int NK>
 __global__ __launch_bounds__(kBlock) void sel_hist_kernel(const double *__restrict__ v, int64_t num,
-                                                          SelState *__restrict__ st, int pass)
+                                                          SelState *__restrict__ st, int pass,
+                                                          const unsigned long long *__restrict__ count_dev = nullptr)
 {
+    if (count_dev) {  // the element count was produced on the device (candidate buffer of pxf_radial_kth)
+        const int64_t c = (int64_t)*count_dev;
+        num = c < num ? c : num;
+    }
     __shared__ unsigned s_hist[NK][kSelBins];
     for (int i = threadIdx.x; i < NK * kSelBins; i += kBlock) (&s_hist[0][0])[i] = 0u;
     __syncthreads();
@@ -175,6 +180,123 @@ struct IndAngleOp {
     }
 };
 
+
+// ---- order statistics of the RADII straight from x, y in ONE pass over the rays ------------------
+// analyses.hpd is 2*median(sqrt((x-cx)^2+(y-cy)^2)).  Materialising the radii and running the six
+// select passes above moves 72 B/ray; the algorithmic minimum is the 16 B/ray of x and y.  This
+// path reaches it for the bulk of the data:
+//   1. a strided SAMPLE of kFsSample rays gives, by radix select on the sample, a bracket [lo, hi]
+//      around the wanted ranks (+-8 sigma of the sample rank);
+//   2. ONE pass over all rays recomputes every radius (same arithmetic as RhoOp), counts those below
+//      lo and appends those inside [lo, hi] to a candidate buffer (wave-aggregated atomics);
+//   3. if the wanted ranks fall inside the bracket and the candidates fit the buffer, the exact
+//      values are selected among the candidates (ranks re-based by the count below lo).
+// The result is the same element np.median would use; if the bracket misses (heavy ties, adversarial
+// order) `ok` stays 0 and the caller falls back to the full path.  mode 1: radii are |y - cy| (hpdY).
+constexpr int kFsSample = 1 << 20;
+
+struct FastSelState {
+    double lohi[2];
+    unsigned long long below, inside, nan_count;
+    int ok;
+};
+
+__device__ __forceinline__ double fs_radius(double x, double y, double cx, double cy, int mode)
+{
+    if (mode == 1) return fabs(y - cy);
+    const double dx = x - cx, dy = y - cy;
+    return sqrt(dx * dx + dy * dy);
+}
+
+__global__ __launch_bounds__(kBlock) void fs_sample_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                           double cx, double cy, int mode, int64_t num, int nsamp,
+                                                           double *__restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nsamp) return;
+    // evenly strided: index floor(i * num / nsamp) (i < 2^20, num < 2^43: the product fits 64 bits)
+    const int64_t j = (int64_t)(((unsigned long long)i * (unsigned long long)num) / (unsigned long long)nsamp);
+    out[i] = fs_radius(mode == 1 ? 0. : x[j], y[j], cx, cy, mode);
+}
+
+constexpr int kFsStage = 2048;  // candidates staged per workgroup in LDS between flushes
+
+__global__ __launch_bounds__(kBlock) void fs_collect_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                            double cx, double cy, int mode, int64_t num,
+                                                            FastSelState *__restrict__ fs, double *__restrict__ cand,
+                                                            long long cap)
+{
+    // Candidates are staged in LDS and appended to the global buffer a block at a time: ONE global
+    // atomic per flush (a single counter hit once per candidate serialises at ~10 ns each -- 8 ms per
+    // 1e8 rays, measured).
+    __shared__ double s_buf[kFsStage];
+    __shared__ unsigned s_n;
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    const double lo = fs->lohi[0], hi = fs->lohi[1];
+    unsigned below = 0, nans = 0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t iters = (num + stride - 1) / stride;  // the same for every thread: barriers inside the loop
+    for (int64_t it = 0; it <= iters; it++) {
+        // flush when the next iteration could overflow the stage, and once after the last iteration
+        const unsigned staged = s_n;
+        const bool last = it == iters;
+        if (staged > (unsigned)(kFsStage - kBlock) || (last && staged)) {
+            __syncthreads();  // everyone has read s_n
+            if (threadIdx.x == 0) s_base = atomicAdd(&fs->inside, (unsigned long long)staged);
+            __syncthreads();
+            const unsigned long long base = s_base;
+            for (unsigned j = threadIdx.x; j < staged; j += kBlock)
+                if ((long long)(base + j) < cap) cand[base + j] = s_buf[j];
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0u;
+        }
+        __syncthreads();
+        if (last) break;
+        const int64_t i = first + it * stride;
+        if (i < num) {
+            const double r = fs_radius(mode == 1 ? 0. : __builtin_nontemporal_load(x + i),
+                                       __builtin_nontemporal_load(y + i), cx, cy, mode);
+            nans += (r != r) ? 1u : 0u;
+            below += (r < lo) ? 1u : 0u;
+            if (r >= lo && r <= hi) s_buf[atomicAdd(&s_n, 1u)] = r;
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        below += __shfl_down(below, off);
+        nans += __shfl_down(nans, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (below) atomicAdd(&fs->below, (unsigned long long)below);
+        if (nans) atomicAdd(&fs->nan_count, (unsigned long long)nans);
+    }
+}
+
+// bracket from the sample select (out2 = the two sample order statistics)
+__global__ void fs_bracket_kernel(FastSelState *__restrict__ fs, const double *__restrict__ out2, int lo_open,
+                                  int hi_open)
+{
+    // a bracket that reaches the end of the sample must reach the end of the data
+    fs->lohi[0] = lo_open ? -INFINITY : out2[0];
+    fs->lohi[1] = hi_open ? INFINITY : out2[1];
+}
+
+// ranks re-based into the candidate buffer; decides whether the fast path is valid
+__global__ void fs_setup_kernel(FastSelState *__restrict__ fs, SelState *__restrict__ st, long long k0, long long k1,
+                                long long cap)
+{
+    const long long below = (long long)fs->below, inside = (long long)fs->inside;
+    const bool ok = inside <= cap && k0 >= below && k1 < below + inside && fs->lohi[0] == fs->lohi[0] &&
+                    fs->lohi[1] == fs->lohi[1];
+    fs->ok = ok ? 1 : 0;
+    st->k[0] = ok ? k0 - below : 0;
+    st->k[1] = ok ? k1 - below : 0;
+    st->nan_count = fs->nan_count;   // NaN anywhere -> NaN out (np.median)
+    if (!ok) fs->inside = 0;         // the select passes below then touch nothing
+}
 
 // ---- weighted quantiles (analyses.hpd with weights, analyses.py:73-97) without a sort ------------
 // The reference sorts the radii, forms cdf = cumsum(w)/sum(w) and takes r[argmin |cdf - q|] for
@@ -468,6 +590,66 @@ int pxf_kth_values(const double *v, int64_t num, const int64_t *k, int32_t nk, d
             hipLaunchKernelGGL((sel_pick_kernel<2>), dim3(1), dim3(64), 0, s, st, p, out_dev);
         }
     }
+    e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+// ---- radii order statistics in one pass over x, y ---------------------------------------------------
+static inline int64_t fs_cap(int64_t num) { const int64_t c = num / 32; return c < (1 << 20) ? (1 << 20) : c; }
+
+size_t pxf_radial_kth_workspace_bytes(int64_t num)
+{
+    if (num < 0) return 0;
+    return 256 + 2 * sizeof(SelState) + 64 + (size_t)kFsSample * sizeof(double) + (size_t)fs_cap(num) * sizeof(double);
+}
+
+int pxf_radial_kth(const double *x, const double *y, double cx, double cy, int32_t mode, int64_t num, const int64_t *k,
+                   int32_t nk, double *out_dev, int32_t *ok_dev, void *workspace, pxf_stream_t stream)
+{
+    if (num <= 0 || !y || (mode == 0 && !x) || (mode != 0 && mode != 1) || !k || nk < 1 || nk > kSelMaxRanks ||
+        !out_dev || !ok_dev || !workspace)
+        return PXF_EINVAL;
+    for (int s = 0; s < nk; s++)
+        if (k[s] < 0 || k[s] >= num) return PXF_EINVAL;
+    const int64_t k0 = k[0] < k[nk - 1] ? k[0] : k[nk - 1], k1 = k[0] < k[nk - 1] ? k[nk - 1] : k[0];
+    hipStream_t s = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    FastSelState *fs = (FastSelState *)w;
+    SelState *sa = (SelState *)(w + 256), *sb = sa + 1;
+    double *tmp2 = (double *)(w + 256 + 2 * sizeof(SelState));
+    double *samp = tmp2 + 8, *cand = samp + kFsSample;
+    const long long cap = (long long)fs_cap(num);
+    hipError_t e = hipMemsetAsync(w, 0, 256 + 2 * sizeof(SelState) + 64, s);
+    if (e != hipSuccess) return hip_fail(e);
+    // 1. sample -> bracket.  Sample ranks of the wanted quantiles +- 8 sigma (sigma = sqrt(p(1-p)/S) <= 1/(2 sqrt S))
+    const int nsamp = num < kFsSample ? (int)num : kFsSample;
+    hipLaunchKernelGGL(fs_sample_kernel, dim3((nsamp + kBlock - 1) / kBlock), dim3(kBlock), 0, s, x, y, cx, cy, (int)mode, num,
+                       nsamp, samp);
+    const double margin = 4.0 * sqrt((double)nsamp) + 2.;
+    long long slo = (long long)floor((double)k0 / (double)num * nsamp - margin);
+    long long shi = (long long)ceil((double)k1 / (double)num * nsamp + margin);
+    if (slo < 0) slo = 0;
+    if (shi > nsamp - 1) shi = nsamp - 1;
+    hipLaunchKernelGGL(sel_init_kernel, dim3(1), dim3(1), 0, s, sa, slo, shi);
+    for (int p = 0; p < kSelPasses; p++) {
+        hipLaunchKernelGGL((sel_hist_kernel<2>), dim3(grid_capped(nsamp)), dim3(kBlock), 0, s, samp, (int64_t)nsamp, sa, p, nullptr);
+        hipLaunchKernelGGL((sel_pick_kernel<2>), dim3(1), dim3(64), 0, s, sa, p, tmp2);
+    }
+    hipLaunchKernelGGL(fs_bracket_kernel, dim3(1), dim3(1), 0, s, fs, tmp2, (int)(slo == 0), (int)(shi == nsamp - 1));
+    // 2. one pass over the rays
+    hipLaunchKernelGGL(fs_collect_kernel, dim3(grid_capped(num)), dim3(kBlock), 0, s, x, y, cx, cy, (int)mode, num, fs, cand, cap);
+    // 3. exact select among the candidates
+    hipLaunchKernelGGL(fs_setup_kernel, dim3(1), dim3(1), 0, s, fs, sb, (long long)k0, (long long)k1, cap);
+    for (int p = 0; p < kSelPasses; p++) {
+        hipLaunchKernelGGL((sel_hist_kernel<2>), dim3(grid_capped(cap)), dim3(kBlock), 0, s, cand, (int64_t)cap, sb, p, &fs->inside);
+        hipLaunchKernelGGL((sel_pick_kernel<2>), dim3(1), dim3(64), 0, s, sb, p, tmp2 + 2);
+    }
+    // results in the caller's rank order, and the validity flag
+    e = hipMemcpyAsync(out_dev, tmp2 + 2 + (k[0] <= k[nk - 1] ? 0 : 1), sizeof(double), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && nk > 1)
+        e = hipMemcpyAsync(out_dev + 1, tmp2 + 2 + (k[0] <= k[nk - 1] ? 1 : 0), sizeof(double), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ok_dev, &fs->ok, sizeof(int), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return hip_fail(e);
     e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }

@@ -821,3 +821,36 @@ def test_southwell_module_matches_reference_southwell_py(golden):
     assert out.shape == want.shape and np.array_equal(np.isnan(out), np.isnan(want))
     assert bits_equal(out, want).all()
     assert (gx[np.isnan(want)] == 100.).all()                 # in-place sentinel, as in the reference
+
+
+@pytest.mark.parametrize("n", [(1 << 22) + 1, 10_000_000])
+def test_one_pass_radial_median_is_exact(n):
+    """hpd / hpdY on large bundles take the one-pass path (sample bracket + candidate select):
+    exactly np.median's value; heavy ties make the bracket overflow and fall back, same answer;
+    NaN anywhere -> NaN."""
+    import pyxfocus_amd.analyses as anal
+    rng = np.random.default_rng(n)
+    x = rng.normal(0., 1., n) * np.exp(rng.normal(0., 1., n))
+    y = rng.normal(.3, 2., n)
+    rays = [dev(np.zeros(1))] * 1 + [dev(x), dev(y)] + [dev(np.zeros(1))] * 7
+    cx, cy = anal.centroid(rays)
+    want = 2. * np.median(np.sqrt((x - cx) ** 2 + (y - cy) ** 2))
+    assert anal._radial_kth(rays, cx, cy, [(n - 1) // 2, n // 2]) is not None       # the fast path held
+    assert anal.hpd(rays) == want
+    assert anal.hpdY(rays) == 2. * np.median(np.abs(y - cy))
+    # other ranks through the same entry (one bracket spans BOTH ranks, so they must be close:
+    # far-apart ranks overflow the candidate buffer and report "did not hold"), reversed order too
+    r = np.sort(np.sqrt((x - cx) ** 2 + (y - cy) ** 2))
+    assert anal._radial_kth(rays, cx, cy, [3 * n // 4 + 2, 3 * n // 4]) == [r[3 * n // 4 + 2], r[3 * n // 4]]
+    assert anal._radial_kth(rays, cx, cy, [n // 4]) == [r[n // 4]]
+    assert anal._radial_kth(rays, cx, cy, [0]) == [r[0]] and anal._radial_kth(rays, cx, cy, [n - 1]) == [r[-1]]
+    assert anal._radial_kth(rays, cx, cy, [3 * n // 4, n // 4]) is None
+    # ties: half the rays on one point -> the bracket is one huge tied run
+    x2, y2 = x.copy(), y.copy()
+    x2[: n // 2 + 5] = 1.25
+    y2[: n // 2 + 5] = -.5
+    rays2 = [rays[0], dev(x2), dev(y2)] + rays[3:]
+    cx2, cy2 = anal.centroid(rays2)
+    assert anal.hpd(rays2) == 2. * np.median(np.sqrt((x2 - cx2) ** 2 + (y2 - cy2) ** 2))
+    x2[7] = np.nan
+    assert np.isnan(anal.hpd([rays[0], dev(x2), dev(y2)] + rays[3:]))
