@@ -319,3 +319,43 @@ def test_argument_validation_through_python_layer():
     with pytest.raises(IndexError):
         import pyxfocus_amd.transformations as tran
         tran.reflect(rays, ind=np.array([99]))
+
+
+def test_two_host_threads_two_streams(port):
+    """The C ABI is stateless and stream-ordered: two host threads tracing different bundles on
+    their own HIP streams at the same time both get the oracle's bits."""
+    import threading
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            rng = np.random.default_rng(100 + tid)
+            c = cases.annulus_rays(rng, 20000 + 1000 * tid, cases.primrad(cases.Z0),
+                                   cases.primrad(cases.Z0 + cases.LMIR), 0.)
+            want = {k: v.copy() for k, v in c.items()}
+            cases.chain_config2(port, want)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(10):
+                    rays = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+                    tran.transform(rays, 0, 0, -(cases.Z0 + 2 * cases.LMIR), 0, 0, 0)
+                    surf.wolterprimary(rays, cases.R0, cases.Z0)
+                    tran.reflect(rays)
+                    surf.woltersecondary(rays, cases.R0, cases.Z0)
+                    tran.reflect(rays)
+                    surf.flat(rays)
+                    st.synchronize()
+                    ok = all(bits_equal(r.cpu().numpy(), want[k]).all() for k, r in zip(ALLCOLS, rays))
+                    results[(tid, rep)] = ok
+        except Exception as e:  # surfaced in the main thread
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 20 and all(results.values())
