@@ -313,7 +313,8 @@ def main():
     out = None
     if rank == 0:
         value = N * n_gpus * K / elapsed
-        out = {"metric": "rays/sec through two-bounce Wolter-I trace", "value": value, "unit": "rays/s",
+        out = {"metric": "rays/sec through two-bounce Wolter-I trace; RMS spot error vs Fortran ref",   # BASELINE.json
+               "value": value, "unit": "rays/s", "rms_pos_err_vs_reference_mm": None,
                "n_gpus": n_gpus, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic",
@@ -338,6 +339,8 @@ def main():
                 return {k: v.cpu().numpy() for k, v in zip(order, r)}
             try:
                 out["cpu_baseline"] = cpu_baseline(gpu_chain)
+                # the metric's second half: RMS ray-position error of the GPU path vs the reference
+                out["rms_pos_err_vs_reference_mm"] = out["cpu_baseline"]["parity_vs_gpu"]["rms_pos_err_mm"]
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
