@@ -76,6 +76,12 @@ def primrad(z, r0=R0, z0=Z0, psi=PSI):
     return math.sqrt(p ** 2 + 2 * p * z + (4 * e ** 2 * p * d) / (e ** 2 - 1))
 
 
+def secrad(z, r0=R0, z0=Z0, psi=PSI):
+    """conicsolve.py:29-37"""
+    p, d, e = wolter_params(r0, z0, psi)
+    return math.sqrt(e ** 2 * (d + z) ** 2 - z ** 2)
+
+
 def noll_orders(nterms):
     """Standard (Noll) ordering consistent with specialFunctions.f95:139-140
     ("Z1 = 1, Z2 = 2 r cos t; sin if odd index, cos if even").  Returns (rorder, aorder) with

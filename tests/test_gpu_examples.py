@@ -1,0 +1,128 @@
+"""The ports under examples/ (reference scripts with torch in place of NumPy on ray columns) against
+the same call sequences through the oracle on the CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import cases
+from util import ALLCOLS
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+NINE = "x y z l m n ux uy uz".split()
+
+
+def _dev(c):
+    return [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+
+
+def _tr(be, c, *a, inverse=False):
+    f = be.transformationsf.itransform if inverse else be.transformationsf.transform
+    f(*[c[k] for k in NINE], *[-float(v) for v in a])       # the wrapper negates (transformations.py:29,63)
+
+
+def _beam(rng, n, halfx, halfy=None, circular=True):
+    c = {k: np.zeros(n) for k in ALLCOLS}
+    if circular:
+        rho, th = np.sqrt(rng.random(n)) * halfx, rng.random(n) * 2 * np.pi
+        c["x"], c["y"] = rho * np.cos(th), rho * np.sin(th)
+    else:
+        c["x"], c["y"] = (rng.random(n) - .5) * 2 * halfx, (rng.random(n) - .5) * 2 * halfy
+    c["n"] += 1.
+    return c
+
+
+@pytest.mark.parametrize("which", ["normal_primary", "transverse_primary", "normal_secondary", "transverse_secondary"])
+def test_wolter_schwarzschild_example(port, which):
+    import wolter_schwarzschild_test as ex
+    r0, z0 = 220., 8400.
+    rng = np.random.default_rng(3)
+    n = 4000
+    transverse = which.startswith("transverse")
+    c = _beam(rng, n, z0, r0, circular=False) if transverse else _beam(rng, n, r0 * 2)
+    fn = {"normal_primary": ex.testNormalPrimary, "transverse_primary": ex.testTransversePrimary,
+          "normal_secondary": ex.testNormalSecondary, "transverse_secondary": ex.testTransverseSecondary}[which]
+    off = 2e-3
+    kw = {"offz": off, "dx": 1.} if transverse else {"offx": off, "dz": 2.}
+    rays, a, b = fn(r0, z0, 1., rays=_dev(c), **kw)
+    # the same sequence through the oracle
+    if transverse:
+        _tr(port, c, 0, 0, 0, 0, np.pi / 2, 0)
+        _tr(port, c, -r0 + 1., 0, -z0, 0, 0, 0)
+        c["n"] = c["n"] + off
+        c["l"] = -np.sqrt(1 - c["n"] ** 2)
+    else:
+        _tr(port, c, 0, 0, -z0 + 2., 0, 0, 0)
+        c["l"] = c["l"] + off
+        c["n"] = -np.sqrt(1 - c["l"] ** 2)
+    start = {k: c[k].copy() for k in "xyz"}
+    f = port.woltsurf.wsprimary if "primary" in which else port.woltsurf.wssecondary
+    alpha = .25 * np.arctan(r0 / z0)              # the wrapper hands the Fortran alpha, not r0 (surfaces.py:339-342)
+    f(*[c[k] for k in NINE], alpha, z0, 1.)
+    got = {k: r.cpu().numpy() for k, r in zip(ALLCOLS, rays)}
+    moved_ref = (c["x"] != start["x"]) | (c["y"] != start["y"]) | (c["z"] != start["z"])
+    moved_gpu = (got["x"] != start["x"]) | (got["y"] != start["y"]) | (got["z"] != start["z"])
+    assert np.array_equal(moved_ref, moved_gpu) and moved_ref.sum() > 0       # the same rays reach the mirror
+    for k in NINE:
+        fin = np.isfinite(c[k])
+        assert np.array_equal(fin, np.isfinite(got[k])), k
+        assert np.abs(got[k][fin] - c[k][fin]).max() <= 2e-8 * (1 + np.abs(c[k][fin]).max()), k
+
+
+def test_ll_pair_trace_example(port):
+    import ll_pair_trace as ex
+    rng = np.random.default_rng(11)
+    n = 3000
+    r1 = cases.primrad(8600., 1000., 8400.)
+    ang = 260. / 1000.
+    c = {k: np.zeros(n) for k in ALLCOLS}                              # sources.subannulus(1000, r1, ang, n), zhat=+1
+    rho = np.sqrt(1000. ** 2 + rng.random(n) * (r1 ** 2 - 1000. ** 2))
+    th = rng.random(n) * ang - ang / 2
+    c["x"], c["y"], c["n"] = rho * np.cos(th), rho * np.sin(th), np.ones(n)
+    xo, yo = np.meshgrid(np.arange(3), np.arange(3))
+    coeff = np.zeros(9)
+    coeff[4], coeff[2] = 2e-4, -1e-4
+    res = (coeff, xo.flatten(), yo.flatten())
+    tilt, despace = 2e-5, .05
+    rms, thru, cx, cy, rays = ex.pairRaytrace(tilt, despace, res, res, rays=_dev(c))
+
+    # ---- the same through the oracle + NumPy wrappers --------------------------------------
+    def vig(c, ind):
+        return {k: np.ascontiguousarray(v[ind]) for k, v in c.items()}
+
+    ax, az = res[2].astype(np.int32), res[1].astype(np.int32)
+    _tr(port, c, 0, 0, 0, np.pi, 0, 0)
+    _tr(port, c, 0, 0, -10000, 0, 0, 0)
+    port.woltsurf.wolterprimll(*[c[k] for k in NINE], 1000., 8400., 8600., 8400., ang, coeff, ax, az)
+    c = vig(c, (c["z"] < 8600.) & (c["z"] > 8400.))
+    numin = float(len(c["x"]))
+    port.transformationsf.reflect(*[c[k] for k in "l m n ux uy uz".split()])
+    sr = cases.secrad(8300., 1000., 8400.)
+    _tr(port, c, sr, 0, 8300, 0, 0, 0)
+    _tr(port, c, 0, 0, despace, 0, tilt, 0)
+    _tr(port, c, sr, 0, 8300, 0, 0, 0, inverse=True)
+    port.woltsurf.woltersecll(*[c[k] for k in NINE], 1000., 8400., 1., 8400., 8200., ang, coeff, ax, az)
+    c = vig(c, (c["z"] < 8400.) & (c["z"] > 8200.))
+    numout = float(len(c["x"]))
+    port.transformationsf.reflect(*[c[k] for k in "l m n ux uy uz".split()])
+    _tr(port, c, sr, 0, 8300, 0, 0, 0)
+    _tr(port, c, 0, 0, despace, 0, tilt, 0, inverse=True)
+    _tr(port, c, sr, 0, 8300, 0, 0, 0, inverse=True)
+    for _ in range(2):                                                   # surfaces.focus (surfaces.py:502-510)
+        l_n, m_n = c["l"] / c["n"], c["m"] / c["n"]
+        bx = np.average(c["x"] * l_n) - np.average(c["x"]) * np.average(l_n)
+        ax_ = np.average(l_n * l_n) - np.average(l_n) ** 2
+        by = np.average(c["y"] * m_n) - np.average(c["y"]) * np.average(m_n)
+        ay = np.average(m_n * m_n) - np.average(m_n) ** 2
+        _tr(port, c, 0, 0, -(bx + by) / (ax_ + ay), 0, 0, 0)
+        port.surfacesf.flat(*[c[k] for k in NINE])
+    assert numin > .5 * n and numout > .5 * numin
+    assert thru == numout / numin and len(rays[1]) == len(c["x"])
+    want_rms = cases.rms_centroid(c["x"], c["y"]) / 8400. * 180 / np.pi * 60 ** 2
+    assert abs(cx - c["x"].mean()) < 1e-8 and abs(cy - c["y"].mean()) < 1e-8
+    assert abs(rms - want_rms) < 1e-6 * max(1., want_rms)
+    assert np.abs(rays[1].cpu().numpy() - c["x"]).max() < 1e-8 and np.abs(rays[2].cpu().numpy() - c["y"]).max() < 1e-8
