@@ -31,10 +31,11 @@ TOL = {"transformationsf.radgrat": (1e-14, 1e-13, {"n": 3e-16}),
 
 
 def bits_equal(a, b):
-    """Bitwise equality of float64 arrays, NaN == NaN (any payload), -0 != +0 NOT enforced."""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    return (a == b) | (np.isnan(a) & np.isnan(b))
+    """Bitwise equality of float64 arrays -- sign of zero included; NaN == NaN with any payload
+    (x86 and gfx950 produce different default-NaN signs: -nan(ind) vs +qNaN)."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float64))
+    return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
 
 
 def assert_cols(fn, got, want, cols, context=""):
