@@ -359,3 +359,32 @@ def test_two_host_threads_two_streams(port):
         t.join()
     assert not errors, errors
     assert len(results) == 20 and all(results.values())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_special_values_bitwise(port, seed):
+    """IEEE corner inputs through every bit-exact entry: +-0, denormals, huge and tiny magnitudes,
+    +-inf and NaN sprinkled over the ray columns.  The GPU must reproduce the CPU oracle bit for bit
+    (sign of zero included; NaN payload aside) -- no flush-to-zero, no fast-math, the reference's
+    operation order.  Newton surfaces included: where a corner value never converges both sides stop
+    at the same iteration cap (the reference itself would not terminate) with the same bits."""
+    rng = np.random.default_rng(900 + seed)
+    special = np.array([0., -0., 5e-324, -5e-324, 2.2250738585072014e-308, 1e-300, -1e-300, 1e300, -1e300,
+                        np.inf, -np.inf, np.nan, 1., -1., .5, 2., 1e-160, 1e160])
+    n_checked = 0
+    for name, fn, cols, args in cases.cases(num=512, seed=77 + seed):
+        if fn not in BITWISE:
+            continue
+        cols = {k: v.copy() for k, v in cols.items()}
+        for k in ALLCOLS:
+            hit = rng.random(cols[k].shape[0]) < .15
+            cols[k][hit] = rng.choice(special, int(hit.sum()))
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, args)
+        t = to_dev(cols)
+        call_gpu(fn, t, args)
+        got = to_host(t)
+        for k in ALLCOLS:
+            assert bits_equal(got[k], want[k]).all(), (name, fn, k, int((~bits_equal(got[k], want[k])).sum()))
+        n_checked += 1
+    assert n_checked >= 25
