@@ -1,6 +1,6 @@
 """HIP-graph capture of a traced call sequence (launch-bound small bundles).
 
-A six-call trace of 1e4 rays costs ~68 us of Python/ctypes/launch overhead per pass and ~12 us when
+A six-call trace of 1e4 rays costs ~47 us of Python/ctypes/launch overhead per pass and ~5 us when
 replayed as a captured HIP graph (tools/latency_probe.py).  Everything the library launches is
 ordered on torch's current stream and allocates nothing, so a trace can be captured as is:
 
