@@ -17,6 +17,7 @@
 // (2n+3)/(n+2), (n+1)/(n+2) sit in LDS and per-iteration reciprocals are shared, so a Newton step
 // costs 6 IEEE divides instead of ~30 (parity for these surfaces is to 1e-10, see tests/util.py).
 #include <math.h>
+#include <stdlib.h>
 
 #include "pxf_kernel.h"
 
@@ -64,11 +65,7 @@ struct WolterSineOp {
 // ---- Legendre-Legendre deformed mirrors --------------------------------------------------------
 constexpr int kLLMax = 256;  // (max axial + 1) * (max az + 1)
 
-template <int KIND>  // 0 primary (:220-288), 1 secondary (:293-379), 2 ellipsoid (:643-718)
-struct LLOp {
-    static constexpr int MAXV = 1;
-    static constexpr unsigned RD = POS | DIR;
-    static constexpr unsigned WR = POS | NRM;
+struct LLData {
     double twop, pp, cst;    // primary
     double e2, twoe2, d;     // secondary
     double aa2, bb2, zfoc;   // ellipsoid: aa**2, bb**2
@@ -76,6 +73,18 @@ struct LLOp {
     double dphi, zspan;      // dphi, zmax-zmin
     int ka, kt;              // highest axial / azimuthal order present
     double cmat[kLLMax];     // C[i*(kt+1)+j], by value in the kernel-argument segment
+};
+
+// KIND: 0 primary (:220-288), 1 secondary (:293-379), 2 ellipsoid (:643-718).
+// KTMAX >= 0: the azimuthal orders are known to be <= KTMAX, so P_j(t), P'_j(t) are generated ONCE
+// per Newton step into registers (fully unrolled) and the double sum costs two multiply-adds per
+// matrix cell (fused; these surfaces are tolerance-parity); KTMAX < 0: any order, the t-recurrence
+// is regenerated for every axial order.
+template <int KIND, int KTMAX = -1>
+struct LLOp : LLData {
+    static constexpr int MAXV = 1;
+    static constexpr unsigned RD = POS | DIR;
+    static constexpr unsigned WR = POS | NRM;
 
     // LDS: [0,kLLMax) the matrix C, then the recurrence coefficients a_n=(2n+3)/(n+2), b_n=(n+1)/(n+2)
     // of P_{n+2} = a_n x P_{n+1} - b_n P_n (so the inner loops multiply instead of dividing)
@@ -116,30 +125,92 @@ struct LLOp {
             const bool zin = !(fabs(zarg) > 1.), tin = !(fabs(targ) > 1.);
             double add = 0., addt = 0., addzz = 0.;
             double pz0 = 1., pz1 = zc, dz0 = 0., dz1 = 1.;  // P_i, P_{i+1}, P'_i, P'_{i+1} in zarg
-            for (int i = 0; i <= ka; i++) {
-                const double Pz = pz0, dPz = zin ? dz0 : 0.;
-                double pt0 = 1., pt1 = tc, dt0 = 0., dt1 = 1.;
-                double s0 = 0., s1 = 0.;  // sum_j C_ij P_j(t), sum_j C_ij P'_j(t)
-                for (int j = 0; j <= kt; j++) {
-                    const double cij = cm[i * (kt + 1) + j];
-                    s0 += cij * pt0;
-                    s1 += cij * (tin ? dt0 : 0.);
-                    const double pn = ra[j] * tc * pt1 - rb[j] * pt0;  // P_{j+2}
-                    const double dn = dt0 + (2 * j + 3) * pt1;                            // P'_{j+2}
-                    pt0 = pt1;
-                    pt1 = pn;
-                    dt0 = dt1;
-                    dt1 = dn;
+            constexpr int NT_ = KTMAX >= 0 ? KTMAX + 1 : 1;
+            double Pt[NT_], Dt[NT_];
+            if constexpr (KTMAX >= 0) {
+                Pt[0] = 1.;
+                Dt[0] = 0.;
+                if constexpr (KTMAX >= 1) {
+                    Pt[1] = tc;
+                    Dt[1] = 1.;
                 }
-                add += Pz * s0;
-                addt += Pz * s1;
-                addzz += dPz * s0;
-                const double pn = ra[i] * zc * pz1 - rb[i] * pz0;
-                const double dn = dz0 + (2 * i + 3) * pz1;
-                pz0 = pz1;
-                pz1 = pn;
-                dz0 = dz1;
-                dz1 = dn;
+#pragma unroll
+                for (int j = 0; j + 2 <= KTMAX; j++) {
+                    if (j + 2 <= kt) {  // wave-uniform
+                        Pt[j + 2] = ra[j] * tc * Pt[j + 1] - rb[j] * Pt[j];
+                        Dt[j + 2] = Dt[j] + (2 * j + 3) * Pt[j + 1];
+                    } else {
+                        Pt[j + 2] = 0.;
+                        Dt[j + 2] = 0.;
+                    }
+                }
+                if (!tin) {
+#pragma unroll
+                    for (int j = 0; j <= KTMAX; j++) Dt[j] = 0.;
+                }
+            }
+            if constexpr (KTMAX >= 0) {
+                // two axial orders per trip: four independent accumulation chains
+                for (int i = 0; i <= ka; i += 2) {
+                    const bool two = i + 1 <= ka;
+                    const double Pz = pz0, dPz = zin ? dz0 : 0.;
+                    const double Pz1 = pz1, dPz1 = zin ? dz1 : 0.;
+                    double s0 = 0., s1 = 0., u0 = 0., u1 = 0.;
+                    const double *row0 = cm + i * (kt + 1), *row1 = two ? row0 + (kt + 1) : row0;
+#pragma unroll
+                    for (int j = 0; j <= KTMAX; j++) {
+                        if (j <= kt) {
+                            const double c0 = row0[j], c1 = row1[j];
+                            s0 = __builtin_fma(c0, Pt[j], s0);   // tolerance-parity surface: FMA allowed here
+                            s1 = __builtin_fma(c0, Dt[j], s1);
+                            u0 = __builtin_fma(c1, Pt[j], u0);
+                            u1 = __builtin_fma(c1, Dt[j], u1);
+                        }
+                    }
+                    add += Pz * s0;
+                    addt += Pz * s1;
+                    addzz += dPz * s0;
+                    if (two) {
+                        add += Pz1 * u0;
+                        addt += Pz1 * u1;
+                        addzz += dPz1 * u0;
+                    }
+                    // advance the z recurrences by two orders
+                    const double pn = ra[i] * zc * pz1 - rb[i] * pz0;
+                    const double dn = dz0 + (2 * i + 3) * pz1;
+                    const double pn2 = ra[i + 1] * zc * pn - rb[i + 1] * pz1;
+                    const double dn2 = dz1 + (2 * i + 5) * pn;
+                    pz0 = pn;
+                    pz1 = pn2;
+                    dz0 = dn;
+                    dz1 = dn2;
+                }
+            } else {
+                for (int i = 0; i <= ka; i++) {
+                    const double Pz = pz0, dPz = zin ? dz0 : 0.;
+                    double s0 = 0., s1 = 0.;  // sum_j C_ij P_j(t), sum_j C_ij P'_j(t)
+                    double pt0 = 1., pt1 = tc, dt0 = 0., dt1 = 1.;
+                    for (int j = 0; j <= kt; j++) {
+                        const double cij = cm[i * (kt + 1) + j];
+                        s0 += cij * pt0;
+                        s1 += cij * (tin ? dt0 : 0.);
+                        const double pn = ra[j] * tc * pt1 - rb[j] * pt0;  // P_{j+2}
+                        const double dn = dt0 + (2 * j + 3) * pt1;                            // P'_{j+2}
+                        pt0 = pt1;
+                        pt1 = pn;
+                        dt0 = dt1;
+                        dt1 = dn;
+                    }
+                    add += Pz * s0;
+                    addt += Pz * s1;
+                    addzz += dPz * s0;
+                    const double pn = ra[i] * zc * pz1 - rb[i] * pz0;
+                    const double dn = dz0 + (2 * i + 3) * pz1;
+                    pz0 = pz1;
+                    pz1 = pn;
+                    dz0 = dz1;
+                    dz1 = dn;
+                }
             }
             const double r2 = y * y + x * x;
             const double ir2 = 1. / r2;
@@ -502,8 +573,7 @@ static Cols cols9(double *x, double *y, double *z, const double *l, const double
     return c;
 }
 
-template <int KIND>
-static int fold_ll(LLOp<KIND> &op, double zmax, double zmin, double dphi, const double *coeff,
+static int fold_ll(LLData &op, double zmax, double zmin, double dphi, const double *coeff,
                    const int32_t *axial, const int32_t *az, int32_t cnum)
 {
     if (cnum < 0 || (cnum > 0 && (!coeff || !axial || !az))) return PXF_EINVAL;
@@ -540,6 +610,31 @@ static int conicplus_run(double *opd, double *x, double *y, double *z, const dou
     for (int j = 0; j < Np; j++) op.p[j] = p[j];
     Cols c = cols9(x, y, z, l, m, n, ux, uy, uz);
     c.p[OPD] = opd;
+    return launch_rays(c, num, mask, stream, op);
+}
+
+// launch with the smallest compile-time bound that covers the azimuthal orders present
+template <int KIND>
+static int ll_launch(const LLData &d, const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream)
+{
+    static const bool force_generic = getenv("PXF_LL_GENERIC") != nullptr;   // dev knob (tools/bench_ops.py A/B)
+    if (!force_generic && d.kt <= 3) {
+        LLOp<KIND, 3> op{};
+        static_cast<LLData &>(op) = d;
+        return launch_rays(c, num, mask, stream, op);
+    }
+    if (!force_generic && d.kt <= 7) {
+        LLOp<KIND, 7> op{};
+        static_cast<LLData &>(op) = d;
+        return launch_rays(c, num, mask, stream, op);
+    }
+    if (!force_generic && d.kt <= 15) {
+        LLOp<KIND, 15> op{};
+        static_cast<LLData &>(op) = d;
+        return launch_rays(c, num, mask, stream, op);
+    }
+    LLOp<KIND, -1> op{};
+    static_cast<LLData &>(op) = d;
     return launch_rays(c, num, mask, stream, op);
 }
 
@@ -582,7 +677,7 @@ int pxf_wolterprimll(double *x, double *y, double *z, const double *l, const dou
                      double zmin, double dphi, const double *coeff, const int32_t *axial, const int32_t *az,
                      int32_t cnum, const uint8_t *mask, pxf_stream_t stream)
 {
-    LLOp<0> op{};
+    LLData op{};
     int rc = fold_ll(op, zmax, zmin, dphi, coeff, axial, az, cnum);
     if (rc != PXF_OK) return rc;
     double p, d, e;
@@ -591,7 +686,7 @@ int pxf_wolterprimll(double *x, double *y, double *z, const double *l, const dou
     op.pp = p * p;
     op.cst = 4 * (e * e) * p * d / (e * e - 1);
     op.tol = PXF_TOL_1EM10;
-    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+    return ll_launch<0>(op, cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream);
 }
 
 int pxf_woltersecll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
@@ -599,7 +694,7 @@ int pxf_woltersecll(double *x, double *y, double *z, const double *l, const doub
                     double zmax, double zmin, double dphi, const double *coeff, const int32_t *axial,
                     const int32_t *az, int32_t cnum, const uint8_t *mask, pxf_stream_t stream)
 {
-    LLOp<1> op{};
+    LLData op{};
     int rc = fold_ll(op, zmax, zmin, dphi, coeff, axial, az, cnum);
     if (rc != PXF_OK) return rc;
     double p, d, e;
@@ -608,7 +703,7 @@ int pxf_woltersecll(double *x, double *y, double *z, const double *l, const doub
     op.twoe2 = 2 * (e * e);
     op.d = d;
     op.tol = (double)1.e-7f;  // :312
-    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+    return ll_launch<1>(op, cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream);
 }
 
 int pxf_ellipsoidwoltll(double *x, double *y, double *z, const double *l, const double *m, const double *n,
@@ -617,7 +712,7 @@ int pxf_ellipsoidwoltll(double *x, double *y, double *z, const double *l, const 
                         const int32_t *axial, const int32_t *az, int32_t cnum, const uint8_t *mask,
                         pxf_stream_t stream)
 {
-    LLOp<2> op{};
+    LLData op{};
     int rc = fold_ll(op, zmax, zmin, dphi, coeff, axial, az, cnum);
     if (rc != PXF_OK) return rc;
     // woltsurf.f95:656-664, host libm
@@ -631,7 +726,7 @@ int pxf_ellipsoidwoltll(double *x, double *y, double *z, const double *l, const 
     op.bb2 = bb * bb;
     op.zfoc = ff - P + z0;
     op.tol = PXF_TOL_1EM10;
-    return launch_rays(cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream, op);
+    return ll_launch<2>(op, cols9(x, y, z, l, m, n, ux, uy, uz), num, mask, stream);
 }
 
 int pxf_wsprimaryback(double *x, double *y, double *z, const double *l, const double *m, const double *n,

@@ -388,3 +388,26 @@ def test_special_values_bitwise(port, seed):
             assert bits_equal(got[k], want[k]).all(), (name, fn, k, int((~bits_equal(got[k], want[k])).sum()))
         n_checked += 1
     assert n_checked >= 25
+
+
+@pytest.mark.parametrize("kt,ka", [(0, 0), (1, 6), (3, 3), (4, 2), (7, 7), (8, 10), (10, 10), (15, 15), (16, 5), (20, 11)])
+def test_legendre_legendre_order_ranges(port, kt, ka):
+    """The Legendre-Legendre kernels are instantiated for azimuthal orders <= 3, <= 7, <= 15 (register-
+    resident P_j) and for any order (regenerated recurrence): every variant against the oracle, with
+    dense random coefficient sets up to the given orders (10 x 10 is what the reference's examples fit)."""
+    rng = np.random.default_rng(1000 * kt + ka)
+    base = {name: (fn, cols, args) for name, fn, cols, args in cases.cases(num=300, seed=99)}
+    nc = (ka + 1) * (kt + 1)
+    ax, az = np.meshgrid(np.arange(ka + 1), np.arange(kt + 1), indexing="ij")
+    coeff = rng.normal(0., 2e-5, nc) / (1 + ax.flatten() + az.flatten())
+    keep = rng.random(nc) < .8
+    keep[-1] = True                                    # the highest orders stay in
+    coeff, ax, az = coeff[keep], ax.flatten()[keep].astype(np.int32), az.flatten()[keep].astype(np.int32)
+    for name in ("wolterprimll", "woltersecll", "ellipsoidwoltll"):
+        fn, cols, args = base[name]
+        args = tuple(args[:-3]) + (coeff, ax, az)
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, args)
+        t = to_dev(cols)
+        call_gpu(fn, t, args)
+        assert_cols(fn, to_host(t), want, ALLCOLS, context="kt=%d ka=%d:%s" % (kt, ka, name))

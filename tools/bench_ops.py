@@ -80,7 +80,12 @@ def main():
     llc = np.array([1e-4, 5e-5, 2e-5])
     lla = np.array([2, 3, 4])
     llz = np.array([0, 1, 2])
-    wave = None
+    a11, z11 = np.meshgrid(np.arange(11), np.arange(11), indexing="ij")
+    ll11c, ll11a, ll11z = rng.normal(0, 1e-5, 121) / (1 + a11.flatten() + z11.flatten()), a11.flatten(), z11.flatten()
+    a8, z8 = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    ll8c, ll8a, ll8z = rng.normal(0, 1e-5, 64) / (1 + a8.flatten() + z8.flatten()), a8.flatten(), z8.flatten()
+    a17, z17 = np.meshgrid(np.arange(6), np.arange(17), indexing="ij")
+    ll17c, ll17a, ll17z = rng.normal(0, 1e-5, 102) / (1 + a17.flatten() + z17.flatten()), a17.flatten(), z17.flatten()
 
     ops = [
         # name, input builder, call, algorithmic B/ray
@@ -95,6 +100,12 @@ def main():
         ("woltersecondary", secondary_in, lambda r: surf.woltersecondary(r, R0, Z0), 96),
         ("woltersine", wolter_in, lambda r: surf.woltersine(r, R0, Z0, 1e-4, .1), 96),
         ("primaryLL", wolter_in, lambda r: surf.primaryLL(r, R0, Z0, Z0 + L, Z0, 2 * np.pi, llc, lla, llz), 96),
+        ("primaryLL 11x11 coeffs (orders <= 10)", wolter_in,
+         lambda r: surf.primaryLL(r, R0, Z0, Z0 + L, Z0, 2 * np.pi, ll11c, ll11a, ll11z), 96),
+        ("primaryLL 8x8 coeffs (orders <= 7)", wolter_in,
+         lambda r: surf.primaryLL(r, R0, Z0, Z0 + L, Z0, 2 * np.pi, ll8c, ll8a, ll8z), 96),
+        ("primaryLL 6x17 coeffs (az order 16: generic kernel)", wolter_in,
+         lambda r: surf.primaryLL(r, R0, Z0, Z0 + L, Z0, 2 * np.pi, ll17c, ll17a, ll17z), 96),
         ("secondaryLL", secondary_in,
          lambda r: surf.secondaryLL(r, R0, Z0, PSI, Z0, Z0 - L, 2 * np.pi, llc, lla, llz), 96),
         ("wsPrimary", wolter_in, lambda r: surf.wsPrimary(r, R0, Z0, PSI), 96),
