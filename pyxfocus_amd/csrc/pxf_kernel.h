@@ -135,8 +135,19 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t b, int64_t nblocks, int
     return t;  // may be >= nblocks for the ragged tail: the caller's bound check drops it
 }
 
+// An Op may ask for a minimum occupancy (waves per SIMD) with `static constexpr int MIN_WAVES`: the
+// second __launch_bounds__ argument caps its VGPR budget accordingly (512 / MIN_WAVES per lane).
+template <class T, class = void>
+struct min_waves {
+    static constexpr int value = 1;
+};
+template <class T>
+struct min_waves<T, decltype((void)T::MIN_WAVES)> {
+    static constexpr int value = T::MIN_WAVES;
+};
+
 template <class Op, int V, bool MASKED, bool NT>
-__global__ __launch_bounds__(kBlock) void ray_kernel(Cols c, int64_t first, int64_t nvec,
+__global__ __launch_bounds__(kBlock, min_waves<Op>::value) void ray_kernel(Cols c, int64_t first, int64_t nvec,
                                                      const uint8_t *__restrict__ mask, Op op, int64_t xcd_chunk)
 {
     op.prologue();  // block-wide setup (LDS staging); no-op for most Ops

@@ -108,9 +108,13 @@ __device__ __forceinline__ void zern_eval(const double2 *__restrict__ tab, doubl
 // conic"; the reference's zernsurf is a pure Zernike sag): the sag of a conic of radius
 // R and constant K is added under the Zernike sum,  F = z - c rho^2/(1+sqrt(1-(K+1) c^2 rho^2)) - S.
 // Parity unpinned; checked against the conic kernel (coeff = 0) and an independent NumPy Newton.
+#ifndef PXF_ZERN_MIN_WAVES
+#define PXF_ZERN_MIN_WAVES(NMAX) ((NMAX) <= 7 ? 3 : 1)
+#endif
 template <int NMAX, bool CONIC = false>
 struct ZernOp {
     static constexpr int MAXV = 1;
+    static constexpr int MIN_WAVES = PXF_ZERN_MIN_WAVES(NMAX);
     static constexpr unsigned RD = POS | DIR | B(OPD);  // opd column only touched when has_opd
     static constexpr unsigned WR = POS | NRM | B(OPD);
     static constexpr int NP = zern_npairs(NMAX);
