@@ -61,7 +61,8 @@ class _Recorder:
 
     def reset(self):
         self.ops = []
-        self.cols = [None] * 10      # tensors by bundle slot
+        self.cols = [None] * 10      # tensors by bundle slot (kept alive until the launch)
+        self.ptrs = [0] * 10         # their device addresses (0 = slot not used yet)
         self.keep = []               # masks / aux columns kept alive until the launch
         self.num = None
         self.dev = None
@@ -75,15 +76,20 @@ class _Recorder:
         if self.num is not None and (num != self.num or cols[0].device != self.dev):
             return False
         aux = None
+        ptrs = self.ptrs
+        new = []
         for t, s in zip(cols, slots):
             if s < 0:
                 aux = t
                 continue
-            if self.cols[s] is not None and self.cols[s].data_ptr() != t.data_ptr():
-                return False
-        for t, s in zip(cols, slots):
-            if s >= 0:
-                self.cols[s] = t
+            p = t.data_ptr()
+            if ptrs[s] != p:
+                if ptrs[s]:
+                    return False         # a different tensor in a slot the program already uses
+                new.append((s, t, p))
+        for s, t, p in new:
+            self.cols[s] = t
+            ptrs[s] = p
         self.num, self.dev = num, cols[0].device
         op = PxfOp()
         op.code = OPCODES[name]
@@ -100,11 +106,14 @@ class _Recorder:
             self.reset()
             return
         ops = (PxfOp * len(self.ops))(*self.ops)
-        ptrs = (C.c_void_p * 10)(*[(t.data_ptr() if t is not None else None) for t in self.cols])
+        ptrs = (C.c_void_p * 10)(*[(p or None) for p in self.ptrs])
         dev = self.dev
-        with torch.cuda.device(dev):
-            rc = _lib.lib().pxf_program_run(ops, len(self.ops), ptrs, self.num,
-                                            torch.cuda.current_stream(dev).cuda_stream)
+        from .native import _stream          # (native imports this module)
+        if dev.index == torch.cuda.current_device():    # the common case: skip the device guard
+            rc = _lib.lib().pxf_program_run(ops, len(self.ops), ptrs, self.num, _stream(dev))
+        else:
+            with torch.cuda.device(dev):
+                rc = _lib.lib().pxf_program_run(ops, len(self.ops), ptrs, self.num, _stream(dev))
         n = len(self.ops)
         self.reset()
         _lib.check(rc, "pxf_program_run")
