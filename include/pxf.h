@@ -344,7 +344,8 @@ int pxf_select_hist(const double *v, int64_t num, int32_t nk, void *workspace, i
 int pxf_select_pick(int32_t nk, void *workspace, int32_t pass, double *out_dev, pxf_stream_t stream);
 
 /* Order statistics of the RADII rho_i = sqrt((x_i-cx)^2+(y_i-cy)^2) (mode 0) or |y_i-cy| (mode 1)
- * straight from x, y in one pass over the rays (analyses.hpd / hpdY = twice their median): a strided
+ * straight from x, y in one pass over the rays (analyses.hpd / hpdY = twice their median,
+ * analyses.py:88-116): a strided
  * sample brackets the wanted ranks, one pass counts the radii below the bracket and collects those
  * inside it, the exact k[j]-th values are selected among the collected ones.  *ok_dev = 1 when the
  * bracket held (then out_dev[j] is exactly the k[j]-th smallest radius; NaN if any radius is NaN),
@@ -419,7 +420,8 @@ int pxf_reconstruct(double *xang, double *yang, int32_t xdim, int32_t ydim, doub
 int pxf_source(int32_t kind, double *const *cols, int64_t num, double p0, double p1, double p2,
                double p3, uint64_t seed, uint64_t first_index, pxf_stream_t stream);
 
-/* Extended kinds 5..11.  `num` rays are generated for global indices first_index .. first_index+num-1
+/* Extended kinds 5..11 (sources.py:173-345, 380-471: xslit, rectArray, convergingbeam[2], gaussianBeam,
+ * fanBeam, circFan).  `num` rays are generated for global indices first_index .. first_index+num-1
  * of a bundle of `total` rays (the grid kinds need the full length: np.linspace(.., total)); the grid
  * kinds reproduce NumPy's linspace/meshgrid positions bit for bit (direction cosines to an ulp of sin/cos), the random ones are distribution-equal. */
 int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total, const double *params,
