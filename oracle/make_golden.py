@@ -283,13 +283,14 @@ def main():
     gy[rad > 1] = np.nan
     blob["southwell/gx"], blob["southwell/gy"] = gx.copy(), gy.copy()
     blob["southwell/out"] = sw.southwell(gx, gy, 1e-12, 1.)
-    tor = _load_by_path("reftorus", os.path.join(REF, "torus.py"))
-    tx, ty, tz = np.array([.3, -1.2, 2.5]), np.array([1.1, .4, -.7]), np.array([2., 3., 1.])
-    blob["torus/xyz"] = np.array([tx, ty, tz])
-    blob["torus/F"] = tor.torusF(tx, ty, tz, 300., 2000.)
-    blob["torus/F2"] = tor.torusF2(tx, ty, tz, 300., 2000.)
-    blob["torus/grad"] = np.array(tor.torusGrad(tx, ty, tz, 300., 2000.))
-    blob["torus/quartic"] = tor.constructQuartic(np.array([1., 2., 3.]), np.array([.1, -.2, .97]), 300., 2000.)
+    grt = _load_by_path("refgrating", os.path.join(REF, "grating.py"))
+    inc, wv, dd = np.array([1.5, 1.7, 2.0]) * np.pi / 180, np.array([2.4e-6, 3.6e-6, 4.2e-6]), 1. / 6033.
+    blob["grating/args"] = np.array([inc, wv])
+    for nm in ("blazeYaw", "blazeAngle", "blazeAngle2"):
+        blob["grating/" + nm] = getattr(grt, nm)(inc, wv, 3, dd)
+    blob["grating/litBetaAlpha"] = np.array(grt.litBetaAlpha(inc, wv, 3, dd))
+    blob["grating/eta"] = grt.eta(inc, 2 * inc)
+    blob["grating/yaw"] = grt.yaw(inc, 2 * inc)
     np.savez_compressed(os.path.join(OUT, "design.npz"), **blob)
     print("design:", len(blob), "arrays")
 

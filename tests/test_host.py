@@ -222,13 +222,13 @@ def test_design_helpers_match_reference_conicsolve(golden):
     assert len(radii) >= 2 and radii[-1] <= 219. < radii[-2] and all(np.diff(radii) < 0)
     import pyxfocus_amd.transformations as tran
     assert np.array_equal(tran.skew(np.array([1., -2., 3.5])), g["skew"])
-    from pyxfocus_amd import torus as tor
-    tx, ty, tz = g["torus/xyz"]
-    assert np.array_equal(tor.torusF(tx, ty, tz, 300., 2000.), g["torus/F"])
-    assert np.array_equal(tor.torusF2(tx, ty, tz, 300., 2000.), g["torus/F2"])
-    assert np.array_equal(np.array(tor.torusGrad(tx, ty, tz, 300., 2000.)), g["torus/grad"])
-    assert np.array_equal(tor.constructQuartic(np.array([1., 2., 3.]), np.array([.1, -.2, .97]), 300., 2000.),
-                          g["torus/quartic"])
+    from pyxfocus_amd import grating as grt
+    inc, wv = g["grating/args"]
+    for nm in ("blazeYaw", "blazeAngle", "blazeAngle2"):
+        assert np.array_equal(getattr(grt, nm)(inc, wv, 3, 1. / 6033.), g["grating/" + nm]), nm
+    assert np.array_equal(np.array(grt.litBetaAlpha(inc, wv, 3, 1. / 6033.)), g["grating/litBetaAlpha"])
+    assert np.array_equal(grt.eta(inc, 2 * inc), g["grating/eta"]) and np.array_equal(grt.yaw(inc, 2 * inc), g["grating/yaw"])
+
 
 
 def test_sellmeier_and_radialgrad_formulas():
