@@ -2,7 +2,9 @@
 Wolter-I pair whose figures carry Legendre-Legendre distortions, with a tilted / despaced
 secondary, vignetting rays that miss the active mirror areas, to best focus.  The coefficient sets
 (`res`, `res2` = (coeff, az order, axial order), module globals in the reference) are arguments
-here; everything else follows the reference line by line."""
+here, the reference's call to `secondaryLL` lacks the `psi` argument its own wrapper requires (1. is
+passed), and the repeated frame changes are factored into two helpers; the sequence of operations
+on the rays is the reference's."""
 import os
 import sys
 
@@ -17,37 +19,48 @@ import pyxfocus_amd.surfaces as surf  # noqa: E402
 import pyxfocus_amd.transformations as tran  # noqa: E402
 
 
-def pairRaytrace(secondaryTilt, despace, res, res2, num=10 ** 3, rays=None):
-    """Returns (rms spot in arcsec, fraction surviving the secondary, cx, cy)."""
-    r1 = surf.con.primrad(8600., 1000., 8400.)
-    ang = 260. / 1000.                                   # arc length over radius is the angular extent
-    if rays is None:
-        rays = sources.subannulus(1000., r1, ang, num)
-    tran.transform(rays, 0, 0, 0, np.pi, 0, 0)           # point in -z
-    tran.transform(rays, 0, 0, -10000, 0, 0, 0)          # converge from above
+R0, Z0 = 1000., 8400.                     # node radius and focal distance of the pair
+ZP, ZS = (8400., 8600.), (8200., 8400.)   # axial extent of the primary and of the secondary
 
-    surf.primaryLL(rays, 1000., 8400., 8600, 8400, ang, res[0], res[2], res[1])
-    ind = torch.logical_and(rays[3] < 8600., rays[3] > 8400.)
-    rays = tran.vignette(rays, ind)
+
+def _keep_between(rays, zlo, zhi):
+    """Drop the rays that landed outside the active mirror area."""
+    return tran.vignette(rays, torch.logical_and(rays[3] < zhi, rays[3] > zlo))
+
+
+def _about_secondary_midplane(rays, fn):
+    """Run fn(rays) in the frame whose origin sits on the secondary's surface at z = 8300."""
+    rmid = surf.con.secrad(8300., R0, Z0)
+    tran.transform(rays, rmid, 0, 8300, 0, 0, 0)
+    fn(rays)
+    tran.itransform(rays, rmid, 0, 8300, 0, 0, 0)
+
+
+def pairRaytrace(secondaryTilt, despace, res, res2, num=10 ** 3, rays=None):
+    """Returns (rms spot in arcsec, fraction of the primary's rays surviving the secondary, cx, cy,
+    rays at best focus).  res / res2 = (coefficients, azimuthal orders, axial orders) of the
+    primary's / secondary's figure error."""
+    ang = 260. / R0                                       # arc length over radius: the angular extent
+    if rays is None:
+        rays = sources.subannulus(R0, surf.con.primrad(ZP[1], R0, Z0), ang, num)
+    tran.transform(rays, 0, 0, 0, np.pi, 0, 0)            # point in -z ...
+    tran.transform(rays, 0, 0, -10000, 0, 0, 0)           # ... and converge from above
+
+    surf.primaryLL(rays, R0, Z0, ZP[1], ZP[0], ang, res[0], res[2], res[1])
+    rays = _keep_between(rays, *ZP)
     numin = float(len(rays[1]))
     tran.reflect(rays)
 
-    # secondary misalignment about its midplane
-    tran.transform(rays, surf.con.secrad(8300., 1000., 8400.), 0, 8300, 0, 0, 0)
-    tran.transform(rays, 0, 0, despace, 0, secondaryTilt, 0)
-    tran.itransform(rays, surf.con.secrad(8300., 1000., 8400.), 0, 8300, 0, 0, 0)
-    surf.secondaryLL(rays, 1000., 8400., 1., 8400., 8200., ang, res2[0], res2[2], res2[1])
-    ind = torch.logical_and(rays[3] < 8400., rays[3] > 8200.)
-    rays = tran.vignette(rays, ind)
+    _about_secondary_midplane(rays, lambda r: tran.transform(r, 0, 0, despace, 0, secondaryTilt, 0))
+    surf.secondaryLL(rays, R0, Z0, 1., ZS[1], ZS[0], ang, res2[0], res2[2], res2[1])
+    rays = _keep_between(rays, *ZS)
     numout = float(len(rays[1]))
     tran.reflect(rays)
-    tran.transform(rays, surf.con.secrad(8300., 1000., 8400.), 0, 8300, 0, 0, 0)
-    tran.itransform(rays, 0, 0, despace, 0, secondaryTilt, 0)
-    tran.itransform(rays, surf.con.secrad(8300., 1000., 8400.), 0, 8300, 0, 0, 0)
+    _about_secondary_midplane(rays, lambda r: tran.itransform(r, 0, 0, despace, 0, secondaryTilt, 0))
 
     surf.focusI(rays)
     cx, cy = anal.centroid(rays)
-    return anal.rmsCentroid(rays) / 8400. * 180 / np.pi * 60 ** 2, numout / numin, cx, cy, rays
+    return anal.rmsCentroid(rays) / Z0 * 180 / np.pi * 60 ** 2, numout / numin, cx, cy, rays
 
 
 if __name__ == "__main__":
