@@ -100,6 +100,53 @@ int main(void)
     hipMemcpy(hc, cm, sizeof(hc), hipMemcpyDeviceToHost);
     const double rms = sqrt(hc[1] / hc[0]);
 
+    /* exact median radius in one pass over x, y (hpd = 2 * median), cross-checked on the host */
+    void *kws;
+    double *kout;
+    int32_t *kok;
+    hipMalloc(&kws, pxf_radial_kth_workspace_bytes(n));
+    hipMalloc((void **)&kout, 2 * sizeof(double));
+    hipMalloc((void **)&kok, sizeof(int32_t));
+    const int64_t kk[2] = {(n - 1) / 2, n / 2};
+    CHECK(pxf_radial_kth(x, y, cx, cy, 0, n, kk, 2, kout, kok, kws, s));
+    double hk[2];
+    int32_t hok;
+    hipMemcpyAsync(hk, kout, sizeof(hk), hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(&hok, kok, sizeof(hok), hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(ha, col[1], n * sizeof(double), hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(hb, col[2], n * sizeof(double), hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    int64_t below = 0, equal = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double dx = ha[i] - cx, dy = hb[i] - cy, r = sqrt(dx * dx + dy * dy);
+        below += r < hk[0];
+        equal += r == hk[0];
+    }
+    const int median_ok = hok == 1 && below <= kk[0] && kk[0] < below + equal;
+
+    /* wavefront sensing: bin the focal-plane slopes on a 16 x 16 lenslet grid, reconstruct */
+    enum { XD = 16, YD = 16 };
+    double *gx, *gy, *gp, *gpc;
+    void *bws;
+    int32_t *sweeps;
+    hipMalloc((void **)&gx, XD * YD * sizeof(double));
+    hipMalloc((void **)&gy, XD * YD * sizeof(double));
+    hipMalloc((void **)&gp, XD * YD * sizeof(double));
+    hipMalloc((void **)&gpc, XD * YD * sizeof(double));
+    hipMalloc(&bws, pxf_southwellbin_workspace_bytes(XD, YD));
+    hipMalloc((void **)&sweeps, sizeof(int32_t));
+    CHECK(pxf_southwellbin(x, y, l, m, n, 4. * rms / XD * 2., gx, gy, gp, XD, YD, bws, s));
+    CHECK(pxf_reconstruct(gy, gx, XD, YD, 1e-12, 1., gp, gpc, 1000, sweeps, s));
+    int32_t hsw;
+    double hg[XD * YD];
+    hipMemcpyAsync(&hsw, sweeps, sizeof(hsw), hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(hg, gpc, sizeof(hg), hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    int valid = 0;
+    for (int i = 0; i < XD * YD; i++) valid += hg[i] != 100.;
+    printf("median_ok=%d hpd_mm=%.6e lenslets_valid=%d sweeps=%d\n", median_ok, hk[0] + hk[1], valid, (int)hsw);
+    if (!median_ok || valid < 4 || hsw < 1) return 7;
+
     /* error returns: no exception, no crash */
     int e1 = pxf_flat(NULL, y, z, l, m, nn, ux, uy, uz, n, NULL, s);
     int e2 = pxf_flat(x, y, z, l, m, nn, ux, uy, uz, -1, NULL, s);

@@ -27,8 +27,8 @@ def test_c_program_builds_against_header():
 
 @pytest.mark.gpu
 def test_c_program_runs_on_gpu():
-    if not os.path.exists(EXE):
-        build()
+    build()                      # always: a stale binary from an earlier source must not be what runs
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi_smoke ok" in out.stdout and "fused_mismatch_columns=0" in out.stdout
+    assert "median_ok=1" in out.stdout and "sweeps=" in out.stdout
