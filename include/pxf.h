@@ -464,13 +464,26 @@ int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total,
 #define PXF_OP_PARAXIALY 20    /* a: F */
 #define PXF_OP_GRAT 21         /* a: d, order*wave ; aux (optional) = per-ray order*wave column */
 #define PXF_OP_REFRACT 22      /* a: n1, n2 */
+#define PXF_OP_TRACEZERN 23    /* a: rad      ; aux = (const double *)&pxf_zern_args_t on the HOST */
+#define PXF_OP_TRACEZERNOPD 24 /* a: rad, nr  ; aux as above.  At most ONE Zernike operation per program, */
+                               /* and such a program holds at most PXF_PROGRAM_MAX_OPS_ZERN operations    */
 #define PXF_PROGRAM_MAX_OPS 32
+#define PXF_PROGRAM_MAX_OPS_ZERN 16
+#define PXF_PROGRAM_ZERN_MAX_ORDER 7 /* highest radial order of a FUSED Zernike trace (PXF_ERANGE above) */
+
+/* host-side coefficient table of a PXF_OP_TRACEZERN[OPD] operation (the arguments of pxf_tracezern) */
+typedef struct pxf_zern_args {
+    const double *coeff;   /* HOST arrays of `arrsize` entries */
+    const int32_t *rorder;
+    const int32_t *aorder;
+    int32_t arrsize;
+} pxf_zern_args_t;
 
 typedef struct pxf_op {
     int32_t code;        /* PXF_OP_* */
     int32_t reserved;    /* must be 0 */
     const uint8_t *mask; /* device uint8[num] or NULL */
-    const double *aux;   /* device float64[num] extra column (RADGRATW wavelengths) or NULL */
+    const double *aux;   /* device float64[num] extra column (RADGRATW wavelengths), NULL, or see TRACEZERN */
     double a[6];         /* scalar arguments */
 } pxf_op_t;
 

@@ -46,6 +46,15 @@ SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5,
          "pxf_paraxial": (1, 2, 4, 5), "pxf_paraxialy": (2, 5), "pxf_grat": (4, 5, 6, -1),
          "pxf_refract": (4, 5, 6, 7, 8, 9)}
 MAX_OPS = 32
+MAX_OPS_ZERN = 16      # PXF_PROGRAM_MAX_OPS_ZERN: a program around a Zernike trace
+ZERN_MAX_ORDER = 7     # PXF_PROGRAM_ZERN_MAX_ORDER: higher radial orders run as their own launch
+ZERN_CODES = {"pxf_tracezern": 23, "pxf_tracezernopd": 24}
+ZERN_SLOTS = {"pxf_tracezern": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_tracezernopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)}
+
+
+class PxfZernArgs(C.Structure):
+    _fields_ = [("coeff", C.POINTER(C.c_double)), ("rorder", C.POINTER(C.c_int32)), ("aorder", C.POINTER(C.c_int32)),
+                ("arrsize", C.c_int32)]
 
 
 class PxfOp(C.Structure):
@@ -63,18 +72,17 @@ class _Recorder:
         self.ops = []
         self.cols = [None] * 10      # tensors by bundle slot (kept alive until the launch)
         self.ptrs = [0] * 10         # their device addresses (0 = slot not used yet)
-        self.keep = []               # masks / aux columns kept alive until the launch
+        self.keep = []               # masks / aux columns / host tables kept alive until the launch
+        self.has_zern = False        # the program holds its (one) Zernike operation
         self.num = None
         self.dev = None
 
-    def try_add(self, name, cols, tail, mask):
-        """Record one call; False if it cannot join the pending program (caller flushes and retries)."""
-        if name not in OPCODES or len(self.ops) >= MAX_OPS:
-            return False
-        slots = SLOTS[name]
+    def _bind(self, cols, slots):
+        """Claim the bundle slots for `cols`; returns (ok, aux) -- not ok when a different tensor
+        already sits in a slot, or the bundle length / device differs from the pending program's."""
         num = cols[0].shape[0]
         if self.num is not None and (num != self.num or cols[0].device != self.dev):
-            return False
+            return False, None
         aux = None
         ptrs = self.ptrs
         new = []
@@ -85,12 +93,21 @@ class _Recorder:
             p = t.data_ptr()
             if ptrs[s] != p:
                 if ptrs[s]:
-                    return False         # a different tensor in a slot the program already uses
+                    return False, None   # a different tensor in a slot the program already uses
                 new.append((s, t, p))
         for s, t, p in new:
             self.cols[s] = t
             ptrs[s] = p
         self.num, self.dev = num, cols[0].device
+        return True, aux
+
+    def try_add(self, name, cols, tail, mask):
+        """Record one call; False if it cannot join the pending program (caller flushes and retries)."""
+        if name not in OPCODES or len(self.ops) >= (MAX_OPS_ZERN if self.has_zern else MAX_OPS):
+            return False
+        ok, aux = self._bind(cols, SLOTS[name])
+        if not ok:
+            return False
         op = PxfOp()
         op.code = OPCODES[name]
         op.mask = mask.data_ptr() if mask is not None else None
@@ -99,6 +116,29 @@ class _Recorder:
             op.a[i] = float(v)
         self.ops.append(op)
         self.keep.extend(t for t in (mask, aux) if t is not None)
+        return True
+
+    def try_add_zern(self, name, cols, tables, rad, nr, mask):
+        """Record a tracezern[opd] call.  `tables` = (coeff, rorder, aorder) host arrays and their ctypes
+        pointers; one Zernike operation per program, and such a program holds at most 16 operations."""
+        if self.has_zern or len(self.ops) >= MAX_OPS_ZERN:
+            return False
+        if len(tables[1]) and int(tables[1].max()) > ZERN_MAX_ORDER:
+            return False
+        ok, _ = self._bind(cols, ZERN_SLOTS[name])
+        if not ok:
+            return False
+        ck, rk, ak, cp, rp, ap = tables
+        za = PxfZernArgs(cp, rp, ap, len(ck))
+        op = PxfOp()
+        op.code = ZERN_CODES[name]
+        op.mask = mask.data_ptr() if mask is not None else None
+        op.aux = C.addressof(za)
+        op.a[0] = float(rad)
+        op.a[1] = float(nr)
+        self.ops.append(op)
+        self.keep.extend(t for t in (mask, za, ck, rk, ak) if t is not None)
+        self.has_zern = True
         return True
 
     def flush(self):

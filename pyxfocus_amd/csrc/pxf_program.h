@@ -1,0 +1,101 @@
+// pxf_program.h -- what the fused-program translation units share: the planned program passed by
+// value to the kernels, the wave-uniform interpreter step `exec_op` (each case is the SAME Op::apply
+// the stand-alone kernels instantiate), and the host planner.  See pxf_program.hip.
+#pragma once
+#include "pxf_ops_surfaces.h"
+#include "pxf_ops_transforms.h"
+
+namespace pxf {
+
+constexpr int kMaxOps = PXF_PROGRAM_MAX_OPS;
+
+struct ProgOp {
+    int code;
+    int flags;  // transform: vector groups to move
+    const uint8_t *mask;
+    const double *aux;
+    double p[9];
+};
+
+struct Program {
+    int nops;
+    unsigned load, store;
+    ProgOp op[kMaxOps];
+};
+static_assert(sizeof(Program) + sizeof(Cols) + 64 <= 4096, "program must fit the kernel-argument segment");
+
+template <class OP, int V>
+__device__ __forceinline__ void run_op(const OP &o, Ray (&r)[V], const bool (&sel)[V])
+{
+    unsigned wm[V];
+    o.template apply<V>(r, sel, wm);
+}
+
+// One operation on the V rays of a thread.  `P` points at the op's nine doubles: the kernel
+// arguments for an ordinary program (wave-uniform -> scalar loads), or the workgroup's LDS copy of
+// the ray's SEGMENT parameters for a segmented program.
+template <int V, bool NT>
+__device__ __forceinline__ void exec_op(int code, int flags, const double *__restrict__ P,
+                                        const double *__restrict__ aux, int64_t vv, Ray (&r)[V],
+                                        const bool (&sel)[V])
+{
+    switch (code) {
+        case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
+        case PXF_OP_FLATOPD: run_op(FlatOp<true>{P[0]}, r, sel); break;
+        case PXF_OP_CONIC: run_op(ConicOp<false>{P[0], P[1], 0.}, r, sel); break;
+        case PXF_OP_CONICOPD: run_op(ConicOp<true>{P[0], P[1], P[2]}, r, sel); break;
+        case PXF_OP_WOLTERPRIMARY: run_op(WolterPrimaryOp<false>{P[0], P[1], P[2], 0.}, r, sel); break;
+        case PXF_OP_WOLTERPRIMARYOPD:
+            run_op(WolterPrimaryOp<true>{P[0], P[1], P[2], P[3]}, r, sel);
+            break;
+        case PXF_OP_WOLTERSECONDARY: run_op(WolterSecondaryOp{P[0], P[1], P[2]}, r, sel); break;
+        case PXF_OP_TRANSFORM:
+            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            break;
+        case PXF_OP_ITRANSFORM:
+            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            break;
+        case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
+        case PXF_OP_RADGRAT: run_op(RadgratOp<false>{P[0], P[1], P[2], P[3], P[4]}, r, sel); break;
+        case PXF_OP_RADGRATW: {
+            double t[V];
+            load_col<V, NT>(aux, vv, t);
+#pragma unroll
+            for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
+            run_op(RadgratOp<true>{P[0], P[1], 0., P[3], P[4]}, r, sel);
+            break;
+        }
+        case PXF_OP_SPOCONE: run_op(SpoConeOp{P[0], P[1], P[2], P[3]}, r, sel); break;
+        case PXF_OP_SPHERE: run_op(SphereCylOp<false, false>{P[0], 0.}, r, sel); break;
+        case PXF_OP_SPHEREOPD: run_op(SphereCylOp<true, false>{P[0], P[1]}, r, sel); break;
+        case PXF_OP_CYL: run_op(SphereCylOp<false, true>{P[0], 0.}, r, sel); break;
+        case PXF_OP_CYLOPD: run_op(SphereCylOp<true, true>{P[0], P[1]}, r, sel); break;
+        case PXF_OP_CYLCONIC: run_op(CylConicOp{P[0], P[1]}, r, sel); break;
+        case PXF_OP_PARAXIAL: run_op(ParaxialOp<false>{P[0]}, r, sel); break;
+        case PXF_OP_PARAXIALY: run_op(ParaxialOp<true>{P[0]}, r, sel); break;
+        case PXF_OP_GRAT:
+            if (aux) {
+                double t[V];
+                load_col<V, NT>(aux, vv, t);
+#pragma unroll
+                for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
+                run_op(GratOp<true>{P[0], 0.}, r, sel);
+            } else {
+                run_op(GratOp<false>{P[0], P[1]}, r, sel);
+            }
+            break;
+        case PXF_OP_REFRACT: run_op(RefractOp{P[0], P[1]}, r, sel); break;
+        default: break;
+    }
+}
+
+// host planner (pxf_program.hip): micro-ops, liveness, load / store sets; `zern_op` receives the index
+// (after dead-op compaction) of the program's Zernike operation, or -1
+int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, int *zern_op = nullptr);
+
+// pxf_program_zern.hip: launch a planned program whose operation `iz` is a Zernike trace
+// (PXF_OP_TRACEZERN[OPD]); `za` is the host-side table of that operation
+int launch_program_zern(const Program &pg, int iz, const pxf_zern_args_t *za, const Cols &c, int64_t num,
+                        pxf_stream_t stream);
+
+}  // namespace pxf

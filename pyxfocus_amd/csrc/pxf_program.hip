@@ -13,92 +13,9 @@
 // bit-identical by construction.  Two rays per thread, 16-byte accesses, NT policy as elsewhere.
 #include <stdlib.h>
 
-#include "pxf_ops_surfaces.h"
-#include "pxf_ops_transforms.h"
+#include "pxf_program.h"
 
 namespace pxf {
-
-constexpr int kMaxOps = PXF_PROGRAM_MAX_OPS;
-
-struct ProgOp {
-    int code;
-    int flags;  // transform: vector groups to move
-    const uint8_t *mask;
-    const double *aux;
-    double p[9];
-};
-
-struct Program {
-    int nops;
-    unsigned load, store;
-    ProgOp op[kMaxOps];
-};
-static_assert(sizeof(Program) + sizeof(Cols) + 64 <= 4096, "program must fit the kernel-argument segment");
-
-template <class OP, int V>
-__device__ __forceinline__ void run_op(const OP &o, Ray (&r)[V], const bool (&sel)[V])
-{
-    unsigned wm[V];
-    o.template apply<V>(r, sel, wm);
-}
-
-// One operation on the V rays of a thread.  `P` points at the op's nine doubles: the kernel
-// arguments for an ordinary program (wave-uniform -> scalar loads), or the workgroup's LDS copy of
-// the ray's SEGMENT parameters for a segmented program.
-template <int V, bool NT>
-__device__ __forceinline__ void exec_op(int code, int flags, const double *__restrict__ P,
-                                        const double *__restrict__ aux, int64_t vv, Ray (&r)[V],
-                                        const bool (&sel)[V])
-{
-    switch (code) {
-        case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
-        case PXF_OP_FLATOPD: run_op(FlatOp<true>{P[0]}, r, sel); break;
-        case PXF_OP_CONIC: run_op(ConicOp<false>{P[0], P[1], 0.}, r, sel); break;
-        case PXF_OP_CONICOPD: run_op(ConicOp<true>{P[0], P[1], P[2]}, r, sel); break;
-        case PXF_OP_WOLTERPRIMARY: run_op(WolterPrimaryOp<false>{P[0], P[1], P[2], 0.}, r, sel); break;
-        case PXF_OP_WOLTERPRIMARYOPD:
-            run_op(WolterPrimaryOp<true>{P[0], P[1], P[2], P[3]}, r, sel);
-            break;
-        case PXF_OP_WOLTERSECONDARY: run_op(WolterSecondaryOp{P[0], P[1], P[2]}, r, sel); break;
-        case PXF_OP_TRANSFORM:
-            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
-            break;
-        case PXF_OP_ITRANSFORM:
-            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
-            break;
-        case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
-        case PXF_OP_RADGRAT: run_op(RadgratOp<false>{P[0], P[1], P[2], P[3], P[4]}, r, sel); break;
-        case PXF_OP_RADGRATW: {
-            double t[V];
-            load_col<V, NT>(aux, vv, t);
-#pragma unroll
-            for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
-            run_op(RadgratOp<true>{P[0], P[1], 0., P[3], P[4]}, r, sel);
-            break;
-        }
-        case PXF_OP_SPOCONE: run_op(SpoConeOp{P[0], P[1], P[2], P[3]}, r, sel); break;
-        case PXF_OP_SPHERE: run_op(SphereCylOp<false, false>{P[0], 0.}, r, sel); break;
-        case PXF_OP_SPHEREOPD: run_op(SphereCylOp<true, false>{P[0], P[1]}, r, sel); break;
-        case PXF_OP_CYL: run_op(SphereCylOp<false, true>{P[0], 0.}, r, sel); break;
-        case PXF_OP_CYLOPD: run_op(SphereCylOp<true, true>{P[0], P[1]}, r, sel); break;
-        case PXF_OP_CYLCONIC: run_op(CylConicOp{P[0], P[1]}, r, sel); break;
-        case PXF_OP_PARAXIAL: run_op(ParaxialOp<false>{P[0]}, r, sel); break;
-        case PXF_OP_PARAXIALY: run_op(ParaxialOp<true>{P[0]}, r, sel); break;
-        case PXF_OP_GRAT:
-            if (aux) {
-                double t[V];
-                load_col<V, NT>(aux, vv, t);
-#pragma unroll
-                for (int k = 0; k < V; k++) r[k].c[AUX] = t[k];
-                run_op(GratOp<true>{P[0], 0.}, r, sel);
-            } else {
-                run_op(GratOp<false>{P[0], P[1]}, r, sel);
-            }
-            break;
-        case PXF_OP_REFRACT: run_op(RefractOp{P[0], P[1]}, r, sel); break;
-        default: break;
-    }
-}
 
 // ANYMASK=false instantiations carry no per-op mask code (no saved copy of the ray -> fewer VGPRs)
 template <int V, bool NT, bool ANYMASK>
@@ -248,8 +165,9 @@ struct Micro {
     bool live;
 };
 
-static int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped)
+int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, int *zern_op)
 {
+    int zern_src = -1;  // index (in the caller's list) of the Zernike operation, if any
     if (nops < 0 || nops > kMaxOps || (nops > 0 && !ops)) return PXF_EINVAL;
     Micro mi[kMaxOps * 3];
     int nm = 0;
@@ -373,6 +291,16 @@ static int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dro
                 o.p[1] = u.a[1];
                 add(DIR | NRM, DIR | NRM, 0, 0);
                 break;
+            case PXF_OP_TRACEZERN:
+            case PXF_OP_TRACEZERNOPD: {
+                const bool wopd = u.code == PXF_OP_TRACEZERNOPD;
+                if (!u.aux || zern_src >= 0) return PXF_EINVAL;  // needs its host table; one per program
+                zern_src = i;
+                o.p[0] = u.a[0];              // rad
+                o.p[1] = wopd ? u.a[1] : 0.;  // nr
+                add(POS | DIR | (wopd ? B(OPD) : 0u), POS | NRM | (wopd ? B(OPD) : 0u), 0, 0);
+                break;
+            }
             default: return PXF_EINVAL;
         }
     }
@@ -402,10 +330,15 @@ static int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dro
         pg.op[m.op].flags |= m.group;
     }
     // compact away fully dead ops
-    int k = 0;
+    int k = 0, zk = -1;
     for (int i = 0; i < nops; i++)
-        if (op_live[i]) pg.op[k++] = pg.op[i];
+        if (op_live[i]) {
+            if (i == zern_src) zk = k;
+            pg.op[k++] = pg.op[i];
+        }
     pg.nops = k;
+    if (zern_op) *zern_op = zk;
+    if (zk >= 0 && k > PXF_PROGRAM_MAX_OPS_ZERN) return PXF_ERANGE;
     pg.load = load;
     pg.store = store;
     if (dropped) *dropped = dead;
@@ -434,10 +367,19 @@ int pxf_program_plan(const pxf_op_t *ops, int32_t nops, uint32_t *load_mask, uin
 int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int64_t num, pxf_stream_t stream)
 {
     Program pg{};
-    int rc = plan_program(ops, nops, pg, nullptr);
+    int iz = -1;
+    int rc = plan_program(ops, nops, pg, nullptr, &iz);
     if (rc != PXF_OK) return rc;
     if (num < 0 || !cols) return PXF_EINVAL;
     if (num == 0 || pg.nops == 0) return PXF_OK;
+    if (iz >= 0) {  // a program around a Zernike trace: its own kernel (one ray per thread, LDS table)
+        Cols cz{};
+        for (int col = 0; col < 10; col++) {
+            cz.p[col] = cols[col];
+            if (((pg.load | pg.store) & B(col)) && !cols[col]) return PXF_EINVAL;
+        }
+        return launch_program_zern(pg, iz, reinterpret_cast<const pxf_zern_args_t *>(pg.op[iz].aux), cz, num, stream);
+    }
     Cols c{};
     bool aligned = true;
     for (int col = 0; col < 10; col++) {
@@ -492,8 +434,10 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
 int pxf_program_params(const pxf_op_t *ops, int32_t nops, double *params_out, int32_t *nlive)
 {
     Program pg{};
-    int rc = plan_program(ops, nops, pg, nullptr);
+    int iz = -1;
+    int rc = plan_program(ops, nops, pg, nullptr, &iz);
     if (rc != PXF_OK) return rc;
+    if (iz >= 0) return PXF_EINVAL;  // a Zernike table is not a per-segment parameter block
     if (!params_out || !nlive) return PXF_EINVAL;
     for (int i = 0; i < pg.nops; i++)
         for (int k = 0; k < 9; k++) params_out[i * 9 + k] = pg.op[i].p[k];
@@ -505,8 +449,10 @@ int pxf_program_run_segments(const pxf_op_t *ops, int32_t nops, const double *se
                              int64_t rays_per_seg, double *const *cols, int64_t num, pxf_stream_t stream)
 {
     Program pg{};
-    int rc = plan_program(ops, nops, pg, nullptr);
+    int iz = -1;
+    int rc = plan_program(ops, nops, pg, nullptr, &iz);
     if (rc != PXF_OK) return rc;
+    if (iz >= 0) return PXF_EINVAL;
     if (num < 0 || !cols || nseg < 1 || !seg_params_dev) return PXF_EINVAL;
     // every workgroup (512 rays) must span at most kMaxSegPerBlock segments; ray pairs stay in one segment
     if (rays_per_seg < 2 || (rays_per_seg & 1) || rays_per_seg * (kMaxSegPerBlock - 1) < 2 * kBlock) return PXF_ERANGE;

@@ -20,182 +20,9 @@
 #include <math.h>
 
 #include "pxf_kernel.h"
+#include "pxf_ops_zernike.h"
 
 namespace pxf {
-
-constexpr int kZernMaxN = 15;
-constexpr int zern_npairs(int nmax) { return ((nmax + 2) / 2) * ((nmax + 3) / 2); }  // #(n,m): n<=nmax
-// index of pair (n,m) (m same parity as n, 0<=m<=n) in the table: pairs of all smaller n, then m/2
-constexpr int zern_pair(int n, int m) { return zern_npairs(n - 1) + m / 2; }
-
-struct ZernTab {
-    double2 a[zern_npairs(kZernMaxN)];  // .x = Ac (cos-type, and m=0), .y = As (sin-type)
-};
-
-// q-recursion coefficients, specialFunctions.f95:195-197
-constexpr double zh3(double n, double m) { return -4 * (m + 2) * (m + 1) / (n + m + 2) / (n - m); }
-constexpr double zh2(double n, double m) { return zh3(n, m) * (n + m + 4) * (n - m - 2) / 4. / (m + 3) + (m + 2); }
-constexpr double zh1(double n, double m)
-{
-    return .5 * (m + 4) * (m + 3) - (m + 4) * zh2(n, m) + zh3(n, m) * (n + m + 6) * (n - m - 4) / 8.;
-}
-
-// Value and gradient of  S(x,y) = sum_i coeff_i Z_i(rho/rad, theta)  from the folded (Ac,As) table:
-// returns S, and the cartesian gradient (dS/dx, dS/dy).  rho == 0 gives NaN, as the reference's
-// division by rho does (zernsurf.f95:63-66).
-template <int NMAX>
-__device__ __forceinline__ void zern_eval(const double2 *__restrict__ tab, double x, double y, double rad,
-                                          double inv_rad, double &S, double &Sx, double &Sy)
-{
-    // one reciprocal per evaluation instead of nine divides (an IEEE fp64 divide is ~11 VALU
-    // instructions; this kernel is VALU-bound and tolerance-parity, so 1/rho is shared)
-    const double rho = sqrt(x * x + y * y);
-    const double inv_rho = 1. / rho;
-    const double ct = x * inv_rho, st = y * inv_rho;  // cos/sin(atan2(y,x))
-    const double rp = rho * inv_rad;
-    const double inv_rp = rad * inv_rho;
-    const double irp2 = inv_rp * inv_rp, irp3 = irp2 * inv_rp;
-    double cm[NMAX + 1], sm[NMAX + 1], pw[NMAX + 1];
-    cm[0] = 1.;
-    sm[0] = 0.;
-    pw[0] = 1.;
-#pragma unroll
-    for (int k = 1; k <= NMAX; k++) {
-        cm[k] = cm[k - 1] * ct - sm[k - 1] * st;
-        sm[k] = sm[k - 1] * ct + cm[k - 1] * st;
-        pw[k] = pw[k - 1] * rp;
-    }
-    double Sv = 0., Sr = 0., St = 0.;
-#pragma unroll
-    for (int nn = 0; nn <= NMAX; nn++) {
-        double R2 = 0., Rp2 = 0., R4 = 0., Rp4 = 0.;  // R_n^{m+2}, R_n^{m+4} of the chain
-#pragma unroll
-        for (int mm = nn; mm >= 0; mm -= 2) {
-            double R, Rp;
-            if (mm == nn) {
-                R = pw[nn];
-                Rp = nn == 0 ? 0. : (double)nn * pw[nn > 0 ? nn - 1 : 0];
-            } else if (mm == nn - 2) {
-                R = (double)nn * pw[nn] - (double)(nn - 1) * pw[nn - 2];
-                const double dnn = (double)nn * pw[nn - 1];
-                const double dn2 = nn - 2 == 0 ? 0. : (double)(nn - 2) * pw[nn > 2 ? nn - 3 : 0];
-                Rp = (double)nn * dnn - (double)(nn - 1) * dn2;
-            } else {
-                const double h3 = zh3(nn, mm), h2 = zh2(nn, mm), h1 = zh1(nn, mm);
-                const double g = h2 + h3 * irp2;
-                R = h1 * R4 + g * R2;
-                Rp = h1 * Rp4 + g * Rp2 - 2 * h3 * irp3 * R2;
-            }
-            R4 = R2;
-            Rp4 = Rp2;
-            R2 = R;
-            Rp2 = Rp;
-            const double2 a = tab[zern_pair(nn, mm)];
-            const double t1 = a.x * cm[mm] + a.y * sm[mm];
-            Sv += R * t1;
-            Sr += Rp * t1;
-            if (mm > 0) St += R * ((double)mm * (a.y * cm[mm] - a.x * sm[mm]));
-        }
-    }
-    const double Srho = Sr * inv_rad;   // dS/drho
-    const double Sth = St * inv_rho;    // (1/rho) dS/dtheta
-    S = Sv;
-    Sx = ct * Srho - st * Sth;
-    Sy = st * Srho + ct * Sth;
-}
-
-// CONIC: EXTENSION without a reference counterpart (BASELINE config 4 names a "Zernike-perturbed
-// conic"; the reference's zernsurf is a pure Zernike sag): the sag of a conic of radius
-// R and constant K is added under the Zernike sum,  F = z - c rho^2/(1+sqrt(1-(K+1) c^2 rho^2)) - S.
-// Parity unpinned; checked against the conic kernel (coeff = 0) and an independent NumPy Newton.
-#ifndef PXF_ZERN_MIN_WAVES
-#define PXF_ZERN_MIN_WAVES(NMAX) ((NMAX) <= 7 ? 3 : 1)
-#endif
-template <int NMAX, bool CONIC = false>
-struct ZernOp {
-    static constexpr int MAXV = 1;
-    static constexpr int MIN_WAVES = PXF_ZERN_MIN_WAVES(NMAX);
-    static constexpr unsigned RD = POS | DIR | B(OPD);  // opd column only touched when has_opd
-    static constexpr unsigned WR = POS | NRM | B(OPD);
-    static constexpr int NP = zern_npairs(NMAX);
-    double2 tab_arg[zern_npairs(NMAX)];  // folded table, by value in the kernel-argument segment
-    double rad, nr;
-    int has_opd;
-    double cc = 0., K1 = 0.;  // conic: curvature 1/R and K+1 (CONIC only)
-
-    __device__ __forceinline__ double2 *lds() const
-    {
-        __shared__ double2 s_tab[zern_npairs(NMAX)];
-        return s_tab;
-    }
-
-    __device__ __forceinline__ void prologue() const
-    {
-        double2 *s = lds();
-        for (int i = threadIdx.x; i < NP; i += kBlock) s[i] = tab_arg[i];
-        __syncthreads();
-    }
-
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-        static_assert(V == 1, "Zernike kernel is one ray per thread");
-        const double2 *__restrict__ tab = lds();
-        double *c = r[0].c;
-        const double l = c[L], m = c[M], n = c[N];
-        double x = c[X], y = c[Y], z = c[Z];
-        double t = 0., Fx = 0., Fy = 0., Fz = 0.;
-        const double inv_rad = 1. / rad;
-        bool act = sel[0];
-        for (int it = 0; act && it < kNewtonCap; it++) {
-            double S, Sx, Sy;
-            zern_eval<NMAX>(tab, x, y, rad, inv_rad, S, Sx, Sy);
-            double F = z - S;   // F = z - sum c_i Z_i ; grad F = (-dS/dx, -dS/dy, 1)
-            Fx = -Sx;
-            Fy = -Sy;
-            Fz = 1.;
-            if (CONIC) {
-                const double r2 = x * x + y * y;
-                const double sq = sqrt(1. - K1 * cc * cc * r2);
-                F -= cc * r2 / (1. + sq);
-                const double g = cc / sq;  // (1/rho) d(sag)/d(rho)
-                Fx -= g * x;
-                Fy -= g * y;
-            }
-            const double Fp = Fx * l + Fy * m + Fz * n;
-            const double delta = -F / Fp;
-            x = x + l * delta;
-            y = y + m * delta;
-            z = z + n * delta;
-            t = t + delta;
-            act = fabs(delta) > PXF_TOL_1EM10;
-        }
-        const double iFp = 1. / sqrt(Fx * Fx + Fy * Fy + Fz * Fz);
-        c[X] = x;
-        c[Y] = y;
-        c[Z] = z;
-        c[UX] = Fx * iFp;
-        c[UY] = Fy * iFp;
-        c[UZ] = Fz * iFp;
-        c[OPD] = c[OPD] + t * nr;  // zernsurf.f95:199 -- once, from the accumulated path length
-        wm[0] = POS | NRM | (has_opd ? B(OPD) : 0u);
-    }
-};
-
-// The opd column is optional.  The generic kernel loads every column an Op declares in RD, so the
-// OPD and plain variants are distinct types that differ only in their RD/WR sets (the plain one
-// never touches the opd column: 96 B/ray instead of 112).
-template <int NMAX, bool WOPD, bool CONIC = false>
-struct ZernOpSel : ZernOp<NMAX, CONIC> {
-    static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
-    static constexpr unsigned WR = POS | NRM | (WOPD ? B(OPD) : 0u);
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-        if (!WOPD) r[0].c[OPD] = 0.;
-        ZernOp<NMAX, CONIC>::template apply<V>(r, sel, wm);
-    }
-};
 
 // zernphase : zernsurf.f95:206-250.  A thin Zernike PHASE plate in the z=0 plane: one evaluation
 // (no Newton); l += dS/dx*wave, m += dS/dy*wave, n renormalised with its sign kept, opd += S*wave.
@@ -203,6 +30,7 @@ struct ZernOpSel : ZernOp<NMAX, CONIC> {
 template <int NMAX>
 struct ZernPhaseOp {
     static constexpr int MAXV = 1;
+    static constexpr int MIN_WAVES = 2;  // stay within 256 registers: see PXF_ZERN_MIN_WAVES
     static constexpr unsigned RD = B(OPD) | B(X) | B(Y) | DIR;
     static constexpr unsigned WR = B(OPD) | DIR;
     double2 tab_arg[zern_npairs(NMAX)];
@@ -216,6 +44,7 @@ struct ZernPhaseOp {
     {
         double2 *s = lds();
         for (int i = threadIdx.x; i < zern_npairs(NMAX); i += kBlock) s[i] = tab_arg[i];
+        zern_h_stage<NMAX>();
         __syncthreads();
     }
     template <int V>
@@ -231,47 +60,6 @@ struct ZernPhaseOp {
         wm[0] = WR;
     }
 };
-
-// ---- host: fold (coeff, rorder, aorder) into the (n,|m|) table ----------------------------
-// `rot`: the set is evaluated at theta+rot (tracezernrot's second set, zernsurf.f95:302): by the
-// angle-addition identities  Ac cos(m(t+rot)) + As sin(m(t+rot))  =
-//   [Ac cos(m rot) + As sin(m rot)] cos(m t) + [As cos(m rot) - Ac sin(m rot)] sin(m t),
-// so a rotated set folds into the SAME table and costs the kernel nothing.  `accumulate` adds to
-// an already folded table.
-static int fold_table(const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
-                      ZernTab &tab, int &nmax, double rot = 0., bool accumulate = false)
-{
-    if (arrsize < 0 || (arrsize > 0 && (!coeff || !rorder || !aorder))) return PXF_EINVAL;
-    if (!accumulate) {
-        for (auto &a : tab.a) a = make_double2(0., 0.);
-        nmax = 0;
-    }
-    const double sqrt_half_f32 = (double)sqrtf(0.5f);  // specialFunctions.f95:225: REAL*4 sqrt(0.5)
-    for (int i = 0; i < arrsize; i++) {
-        const int n = rorder[i], mm = aorder[i], m = mm < 0 ? -mm : mm;
-        if (n < 0 || m > n || ((n - m) & 1)) return PXF_EINVAL;  // the reference reads garbage here
-        if (n > kZernMaxN) return PXF_ERANGE;
-        if (n > nmax) nmax = n;
-        const double norm = sqrt(2. * (n + 1));
-        double2 &a = tab.a[zern_pair(n, m)];
-        double ac = 0., as = 0.;
-        if (mm < 0)
-            as = coeff[i] * norm;
-        else if (mm > 0)
-            ac = coeff[i] * norm;
-        else
-            ac = coeff[i] * (norm * sqrt_half_f32);
-        if (rot != 0. && m > 0) {
-            const double cr = cos(m * rot), sr = sin(m * rot);
-            const double ac2 = ac * cr + as * sr, as2 = as * cr - ac * sr;
-            ac = ac2;
-            as = as2;
-        }
-        a.x += ac;
-        a.y += as;
-    }
-    return PXF_OK;
-}
 
 template <int NMAX, bool WOPD, bool CONIC = false>
 static int launch_nmax(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream,

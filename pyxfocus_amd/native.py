@@ -293,17 +293,40 @@ def _zern_tables(coeff, rorder, aorder):
     return (ck, rk, ak, ck.ctypes.data_as(_lib._DP), rk.ctypes.data_as(_lib._IP), ak.ctypes.data_as(_lib._IP))
 
 
+def _record_zern(name, cols, tables, rad, nr, mask):
+    """Inside a fused() block: record the Zernike trace into the pending program (True), or make
+    room for it by flushing; False = run it as a stand-alone launch."""
+    rec = fused.active()
+    if rec is None:
+        return False
+    num, dev = _check_cols(cols, name)
+    _mask_ptr(mask, num, dev, name)
+    if num == 0:
+        return True
+    if rec.try_add_zern(name, cols, tables, rad, nr, mask):
+        return True
+    rec.flush()
+    return rec.try_add_zern(name, cols, tables, rad, nr, mask)
+
+
 def tracezern(x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, mask=None):
-    ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    tables = _zern_tables(coeff, rorder, aorder)
+    cols = (x, y, z, l, m, n, ux, uy, uz)
+    if _record_zern("pxf_tracezern", cols, tables, rad, 0., mask):
+        return
+    ck, rk, ak, cp, rp, ap = tables
     fused.flush()
-    _call("pxf_tracezern", (x, y, z, l, m, n, ux, uy, uz), (cp, rp, ap, len(ck), float(rad)), mask)
+    _call("pxf_tracezern", cols, (cp, rp, ap, len(ck), float(rad)), mask)
 
 
 def tracezernopd(opd, x, y, z, l, m, n, ux, uy, uz, coeff, rorder, aorder, rad, nr, mask=None):
-    ck, rk, ak, cp, rp, ap = _zern_tables(coeff, rorder, aorder)
+    tables = _zern_tables(coeff, rorder, aorder)
+    cols = (opd, x, y, z, l, m, n, ux, uy, uz)
+    if _record_zern("pxf_tracezernopd", cols, tables, rad, nr, mask):
+        return
+    ck, rk, ak, cp, rp, ap = tables
     fused.flush()
-    _call("pxf_tracezernopd", (opd, x, y, z, l, m, n, ux, uy, uz),
-          (cp, rp, ap, len(ck), float(rad), float(nr)), mask)
+    _call("pxf_tracezernopd", cols, (cp, rp, ap, len(ck), float(rad), float(nr)), mask)
 
 
 def tracezernconic(opd, x, y, z, l, m, n, ux, uy, uz, R, K, coeff, rorder, aorder, rad, nr=0., mask=None):

@@ -278,3 +278,92 @@ def test_capture_replays_trace_as_hip_graph():
         torch.cuda.synchronize()
         for w, r in zip(want, rays):
             assert bits_equal(r.cpu().numpy(), w.cpu().numpy()).all(), rep
+
+
+def _zern_bundle(n, seed):
+    rng = np.random.default_rng(seed)
+    c = {k: np.zeros(n) for k in ALLCOLS}
+    rho, th = 45. * np.sqrt(rng.random(n)), rng.random(n) * 2 * np.pi
+    c["x"], c["y"], c["z"] = rho * np.cos(th), rho * np.sin(th), np.full(n, 10.)
+    c["l"] = np.full(n, .01)
+    c["n"] = -np.sqrt(1 - c["l"] ** 2)
+    return c
+
+
+@pytest.mark.parametrize("nterms,nr", [(36, None), (36, 1.5), (10, None), (66, None), (120, 1.2)])
+def test_fused_program_around_a_zernike_trace(nterms, nr):
+    """BASELINE config 4 as ONE launch: transform -> zernsurf -> reflect -> flat inside fused() equals
+    the four stand-alone launches (the Zernike arithmetic is tolerance-parity, the other operations
+    are the same bits given the same inputs), for the instantiated order ranges and the OPD variant;
+    radial orders above 7 are not fused (their trace stays its own launch inside the block)."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    rng = np.random.default_rng(nterms)
+    ro, ao = cases.noll_orders(nterms)
+    coeff = rng.normal(0, 1e-3, nterms) / (1 + np.asarray(ro))
+    coeff[0] = 0.
+    c = _zern_bundle(20001, 5)
+
+    def chain(rays):
+        tran.transform(rays, .5, -.25, 0., 1e-3, -2e-3, .1)
+        surf.zernsurf(rays, coeff, 50., rorder=ro, aorder=ao, nr=nr)
+        tran.reflect(rays)
+        surf.flat(rays, nr=nr)
+
+    a, b = dev_rays(c), dev_rays(c)
+    chain(a)
+    with pxf.fused() as rec:
+        chain(b)
+    if max(ro) <= 7:
+        assert rec.launches == 1 and rec.fused_ops == 4
+    else:           # orders above 7 are traced by their own launch between two programs
+        assert rec.launches == 2 and rec.fused_ops == 3
+    for k, u, v in zip(ALLCOLS, a, b):
+        u, v = u.cpu().numpy(), v.cpu().numpy()
+        assert np.array_equal(np.isnan(u), np.isnan(v)), k
+        f = ~np.isnan(u)
+        # 120 terms (n <= 14): Newton converges slowly on the oblique rays, and two roundings of the same
+        # evaluation may stop one step apart -- by the reference's own 1e-10 stopping step
+        tol = 1e-12 if nterms <= 66 else 2e-9
+        assert np.abs(u[f] - v[f]).max() <= tol * (1 + np.abs(u[f]).max()), (k, np.abs(u[f] - v[f]).max())
+
+
+def test_fused_zernike_masks_limits_and_liveness():
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    ro, ao = cases.noll_orders(21)
+    coeff = np.random.default_rng(3).normal(0, 1e-3, 21)
+    coeff[0] = 0.
+    c = _zern_bundle(5000, 9)
+    # an opd column that is live around a plain (non-OPD) Zernike trace must come through untouched
+    a, b = dev_rays(c), dev_rays(c)
+    for rays, ctx in ((a, None), (b, pxf.fused)):
+        def chain():
+            surf.flat(rays, nr=1.3)                       # writes opd
+            tran.transform(rays, 0, 0, -10., 0, 0, 0)
+            surf.zernsurf(rays, coeff, 50., rorder=ro, aorder=ao)
+            tran.reflect(rays)
+        if ctx:
+            with ctx():
+                chain()
+        else:
+            chain()
+    assert bits_equal(a[0].cpu().numpy(), b[0].cpu().numpy()).all() and float(a[0].abs().max()) > 0
+    for u, v in zip(a[1:], b[1:]):
+        assert np.abs(u.cpu().numpy() - v.cpu().numpy()).max() < 1e-11
+    # two Zernike traces in one block -> two launches; 20 operations around one -> split at 16
+    r = dev_rays(c)
+    with pxf.fused() as rec:
+        surf.zernsurf(r, coeff, 50., rorder=ro, aorder=ao)
+        tran.reflect(r)
+        tran.transform(r, 0, 0, -5., 0, 0, 0)
+        surf.zernsurf(r, coeff, 50., rorder=ro, aorder=ao)
+    assert rec.launches == 2
+    r = dev_rays(c)
+    with pxf.fused() as rec:
+        surf.zernsurf(r, coeff, 50., rorder=ro, aorder=ao)
+        for i in range(20):
+            tran.transform(r, 1e-3, 0, 0, 0, 0, 1e-4)
+    assert rec.launches == 2 and rec.fused_ops == 21

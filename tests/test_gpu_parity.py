@@ -411,3 +411,61 @@ def test_legendre_legendre_order_ranges(port, kt, ka):
         t = to_dev(cols)
         call_gpu(fn, t, args)
         assert_cols(fn, to_host(t), want, ALLCOLS, context="kt=%d ka=%d:%s" % (kt, ka, name))
+
+
+@pytest.mark.parametrize("nmax", list(range(1, 16)))
+def test_zernike_every_radial_order(port, nmax):
+    """One kernel instantiation per maximum radial order 1..15: each against the oracle, for tracezern,
+    tracezernOPD, zernphase and the fused-program variant.  (Regression: instantiations that needed more
+    than 256 registers per lane -- orders 10..15 -- were miscompiled: the compiler parks values in AGPRs
+    there, and e.g. order 13 came back 1.7e-10 mm off in z while 12 and 14 agreed to 1e-17.  All
+    Zernike kernels are now held to two waves per SIMD, i.e. 256 registers.)"""
+    import pyxfocus_amd as pxf
+    from pyxfocus_amd import native
+    rng = np.random.default_rng(40 + nmax)
+    nterms = (nmax + 1) * (nmax + 2) // 2
+    ro, ao = cases.noll_orders(nterms)
+    assert max(ro) == nmax
+    ro, ao = np.asarray(ro, np.int32), np.asarray(ao, np.int32)
+    coeff = rng.normal(0, 1e-3, nterms) / (1 + ro)
+    coeff[0] = 0.
+    n = 3001
+    c = {k: np.zeros(n) for k in ALLCOLS}
+    rho, th = 1. + 44. * np.sqrt(rng.random(n)), rng.random(n) * 2 * np.pi
+    c["x"], c["y"], c["z"] = rho * np.cos(th), rho * np.sin(th), np.full(n, 10.)
+    c["l"], c["m"] = np.full(n, .01), rng.normal(0, 1e-3, n)
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    nine = ALLCOLS[1:]
+
+    def check(got, want, what):
+        for k in ALLCOLS:
+            g, w = got[k], want[k]
+            assert np.array_equal(np.isnan(g), np.isnan(w)), (what, k)
+            f = ~np.isnan(w)
+            assert np.abs(g[f] - w[f]).max() <= 1e-12 * (1 + np.abs(w[f]).max()), (what, k, np.abs(g[f] - w[f]).max())
+
+    # tracezern, stand-alone and as a fused program
+    want = {k: v.copy() for k, v in c.items()}
+    port.zernsurf.tracezern(*[want[k] for k in nine], coeff, ro, ao, 50.)
+    t = to_dev(c)
+    native.zernsurf.tracezern(*[t[k] for k in nine], coeff, ro, ao, 50.)
+    check(to_host(t), want, "tracezern")
+    t = to_dev(c)
+    with pxf.fused() as rec:
+        native.zernsurf.tracezern(*[t[k] for k in nine], coeff, ro, ao, 50.)
+    assert rec.launches == (1 if nmax <= 7 else 0)          # orders above 7 are not fused
+    check(to_host(t), want, "tracezern fused")
+    # tracezernOPD
+    want = {k: v.copy() for k, v in c.items()}
+    port.zernsurf.tracezernopd(*[want[k] for k in ALLCOLS], coeff, ro, ao, 50., 1.4)
+    t = to_dev(c)
+    native.zernsurf.tracezernopd(*[t[k] for k in ALLCOLS], coeff, ro, ao, 50., 1.4)
+    check(to_host(t), want, "tracezernopd")
+    # zernphase (rays in the z = 0 plane)
+    c2 = {k: v.copy() for k, v in c.items()}
+    c2["z"][:] = 0.
+    want = {k: v.copy() for k, v in c2.items()}
+    port.zernsurf.zernphase(*[want[k] for k in ALLCOLS], coeff, ro, ao, 50., 1e-3)
+    t = to_dev(c2)
+    native.zernsurf.zernphase(*[t[k] for k in ALLCOLS], coeff, ro, ao, 50., 1e-3)
+    check(to_host(t), want, "zernphase")

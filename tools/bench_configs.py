@@ -138,6 +138,35 @@ def config4(n, reps, nterms=36):
     res["eager"] = {"ms": best[0], "rays_per_s": n / (best[0] * 1e-3), "kernels": best[1]}
     res["zernsurf_rays_per_s"] = n / (z["ms"] * 1e-3)
     res["zernsurf_hbm_frac_of_8TBps"] = z["GBps"] / 8000.
+    # the same three calls as ONE launch (program kernel around the Zernike trace; 120 B/ray)
+    fbest = None
+    for r in range(reps + 1):
+        rays = sources.circularbeam(50., n, rng="philox", seed=40 + r)
+        rays[3].fill_(10.)
+        rays[4].fill_(0.01)
+        rays[6].fill_(-math.sqrt(1 - 1e-4))
+        chk = None
+        if r == reps:
+            chk = [c.clone() for c in rays]
+            surf.zernsurf(chk, coeff, 50., rorder=ro, aorder=ao)
+            tran.reflect(chk)
+            surf.flat(chk)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        with pxf.fused():
+            surf.zernsurf(rays, coeff, 50., rorder=ro, aorder=ao)
+            tran.reflect(rays)
+            surf.flat(rays)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b)
+        if r > 0 and (fbest is None or ms < fbest):
+            fbest = ms
+        if chk is not None:
+            res["fused_max_abs_diff_vs_eager"] = max(float(torch.nan_to_num(u - v).abs().max()) for u, v in zip(rays, chk))
+        del rays
+    res["fused"] = {"ms": fbest, "rays_per_s": n / (fbest * 1e-3), "launches": 1 if int(ro.max()) <= 7 else 3}
     return res
 
 

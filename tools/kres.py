@@ -13,11 +13,13 @@ for line in out.splitlines():
     if m:
         cur = {"name": subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()}
         rows.append(cur)
-    for k in ["VGPRs", "AGPRs", "ScratchSize", "Occupancy", "TotalSGPRs", "LDS Size"]:
-        m = re.search(k + r"[^:]*: (\d+)", line)
+    for k in ["SGPRs Spill", "VGPRs Spill", "VGPRs", "AGPRs", "ScratchSize", "Occupancy", "TotalSGPRs", "LDS Size"]:
+        m = re.search(r"remark:\s+" + re.escape(k) + r"[^:]*: (\d+)", line)
         if m and cur is not None:
             cur.setdefault(k, m.group(1))
+            break
 for r in rows:
     if filt in r["name"]:
-        print("%-78s V%-4s S%-4s scr%-4s occ%-2s lds%s" % (r["name"][:78], r.get("VGPRs"), r.get("TotalSGPRs"),
-              r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS Size")))
+        print("%-78s V%-4s A%-3s S%-4s scr%-4s occ%-2s lds%-5s sspill%-3s vspill%s" % (
+            r["name"][:78], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"),
+            r.get("Occupancy"), r.get("LDS Size"), r.get("SGPRs Spill"), r.get("VGPRs Spill")))
