@@ -72,6 +72,92 @@ __device__ __forceinline__ void zern_h_stage()  // call before the block-wide ba
     }
 }
 
+// The same evaluation with RUN-TIME loops and no per-thread arrays, for the high orders (n >= kZernLoopFrom)
+// whose fully unrolled form needs more registers than a lane has (heavy spills; several spilled
+// instantiations were found to return wrong results).  cos/sin(n theta) ascend with n by the
+// angle-addition recurrence (three consecutive multiples are kept), and within a chain of fixed n
+// they DEscend by two with  cos((m-2)t) = 2 cos(2t) cos(m t) - cos((m+2)t)  (same for sin); the
+// powers rho'^n .. rho'^(n-3) are a sliding window.  Same radial q-recursion, same accumulation order.
+constexpr int kZernLoopFrom = 9;
+
+__device__ __forceinline__ void zern_eval_loop(const double2 *__restrict__ tab, const double (*__restrict__ hq)[3],
+                                               int nmax, double x, double y, double rad, double inv_rad, double &S,
+                                               double &Sx, double &Sy)
+{
+#pragma clang fp contract(fast)
+    const double rho = sqrt(x * x + y * y);
+    const double inv_rho = 1. / rho;
+    const double ct = x * inv_rho, st = y * inv_rho;
+    const double rp = rho * inv_rad;
+    const double inv_rp = rad * inv_rho;
+    const double irp2 = inv_rp * inv_rp, irp3 = irp2 * inv_rp;
+    const double c2t = ct * ct - st * st;  // cos(2 theta)
+    // (cos, sin) of n*theta, (n+1)*theta, (n+2)*theta for the current n
+    double cn = 1., sn = 0., cn1 = ct, sn1 = st, cn2 = c2t, sn2 = 2. * st * ct;
+    // rho'^n, rho'^(n-1), rho'^(n-2), rho'^(n-3) (entries below the zeroth power are never used)
+    double p0 = 1., p1 = 0., p2 = 0., p3 = 0.;
+    double Sv = 0., Sr = 0., St = 0.;
+    int pair = 0;  // index of (n, m = n & 1) in the table; pairs of one n are consecutive, m ascending
+#pragma unroll 1
+    for (int nn = 0; nn <= nmax; nn++) {
+        const int npn = nn / 2 + 1;  // pairs of this n: m = n, n-2, ... down to n & 1
+        double R2 = 0., Rp2 = 0., R4 = 0., Rp4 = 0.;
+        double cm = cn, sm = sn, cmp = cn2, smp = sn2;  // at m and at m+2
+#pragma unroll 1
+        for (int k = 0; k < npn; k++) {
+            const int mm = nn - 2 * k;
+            double R, Rp;
+            if (k == 0) {
+                R = p0;
+                Rp = nn == 0 ? 0. : (double)nn * p1;
+            } else if (k == 1) {
+                R = (double)nn * p0 - (double)(nn - 1) * p2;
+                const double dnn = (double)nn * p1;
+                const double dn2 = nn - 2 == 0 ? 0. : (double)(nn - 2) * p3;
+                Rp = (double)nn * dnn - (double)(nn - 1) * dn2;
+            } else {
+                const double *h = hq[pair + mm / 2];
+                const double h1 = h[0], h2 = h[1], h3 = h[2];
+                const double g = h2 + h3 * irp2;
+                R = h1 * R4 + g * R2;
+                Rp = h1 * Rp4 + g * Rp2 - 2 * h3 * irp3 * R2;
+            }
+            R4 = R2;
+            Rp4 = Rp2;
+            R2 = R;
+            Rp2 = Rp;
+            const double2 a = tab[pair + mm / 2];
+            const double t1 = a.x * cm + a.y * sm;
+            Sv += R * t1;
+            Sr += Rp * t1;
+            if (mm > 0) St += R * ((double)mm * (a.y * cm - a.x * sm));
+            // step m -> m-2
+            const double cd = 2. * c2t * cm - cmp, sd = 2. * c2t * sm - smp;
+            cmp = cm;
+            smp = sm;
+            cm = cd;
+            sm = sd;
+        }
+        pair += npn;
+        // n -> n+1
+        cn = cn1;
+        sn = sn1;
+        cn1 = cn2;
+        sn1 = sn2;
+        cn2 = cn1 * ct - sn1 * st;
+        sn2 = sn1 * ct + cn1 * st;
+        p3 = p2;
+        p2 = p1;
+        p1 = p0;
+        p0 = p0 * rp;
+    }
+    const double Srho = Sr * inv_rad;
+    const double Sth = St * inv_rho;
+    S = Sv;
+    Sx = ct * Srho - st * Sth;
+    Sy = st * Srho + ct * Sth;
+}
+
 // Value and gradient of  S(x,y) = sum_i coeff_i Z_i(rho/rad, theta)  from the folded (Ac,As) table:
 // returns S, and the cartesian gradient (dS/dx, dS/dy).  rho == 0 gives NaN, as the reference's
 // division by rho does (zernsurf.f95:63-66).
@@ -80,6 +166,10 @@ __device__ __forceinline__ void zern_eval(const double2 *__restrict__ tab, doubl
                                           double inv_rad, double &S, double &Sx, double &Sy)
 {
 #pragma clang fp contract(fast)
+    if constexpr (NMAX >= kZernLoopFrom) {
+        zern_eval_loop(tab, zern_h_lds<NMAX, HLDS>(), NMAX, x, y, rad, inv_rad, S, Sx, Sy);
+        return;
+    }
     // one reciprocal per evaluation instead of nine divides (an IEEE fp64 divide is ~11 VALU
     // instructions; this kernel is VALU-bound and tolerance-parity, so 1/rho is shared)
     const double rho = sqrt(x * x + y * y);
