@@ -105,6 +105,8 @@ class _Recorder:
         """Record one call; False if it cannot join the pending program (caller flushes and retries)."""
         if name not in OPCODES or len(self.ops) >= (MAX_OPS_ZERN if self.has_zern else MAX_OPS):
             return False
+        if self.has_zern and mask is not None:       # no ind= masks in a program around a Zernike trace
+            return False
         ok, aux = self._bind(cols, SLOTS[name])
         if not ok:
             return False
@@ -121,7 +123,7 @@ class _Recorder:
     def try_add_zern(self, name, cols, tables, rad, nr, mask):
         """Record a tracezern[opd] call.  `tables` = (coeff, rorder, aorder) host arrays and their ctypes
         pointers; one Zernike operation per program, and such a program holds at most 16 operations."""
-        if self.has_zern or len(self.ops) >= MAX_OPS_ZERN:
+        if self.has_zern or len(self.ops) >= MAX_OPS_ZERN or mask is not None or any(o.mask for o in self.ops):
             return False
         if len(tables[1]) and int(tables[1].max()) > ZERN_MAX_ORDER:
             return False

@@ -91,18 +91,15 @@ static int launch_zern_nmax(const ProgramZ &pz, int iz, const ZernTab &tab, cons
     zop.has_opd = pz.op[iz].code == PXF_OP_TRACEZERNOPD;
     hipStream_t s = (hipStream_t)stream;
     const int g = grid_for(num);
-    bool anymask = false;
-    for (int i = 0; i < pz.nops; i++) anymask |= pz.op[i].mask != nullptr;
-#define PXF_ZLAUNCH(T, A) \
-    hipLaunchKernelGGL((program_zern_kernel<NMAX, T, A>), dim3(g), dim3(kBlock), 0, s, c, num, pz, zop, iz)
-    if (use_nt(num)) {
-        if (anymask) PXF_ZLAUNCH(true, true);
-        else PXF_ZLAUNCH(true, false);
-    } else {
-        if (anymask) PXF_ZLAUNCH(false, true);
-        else PXF_ZLAUNCH(false, false);
-    }
-#undef PXF_ZLAUNCH
+    // no `ind=` masks in a Zernike program: the saved copy of the ray that a masked operation needs would
+    // push this kernel deep into register spills (46 vector + 90 scalar registers) -- the caller runs
+    // such a sequence as separate launches
+    for (int i = 0; i < pz.nops; i++)
+        if (pz.op[i].mask != nullptr) return PXF_ERANGE;
+    if (use_nt(num))
+        hipLaunchKernelGGL((program_zern_kernel<NMAX, true, false>), dim3(g), dim3(kBlock), 0, s, c, num, pz, zop, iz);
+    else
+        hipLaunchKernelGGL((program_zern_kernel<NMAX, false, false>), dim3(g), dim3(kBlock), 0, s, c, num, pz, zop, iz);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }

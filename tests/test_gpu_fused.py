@@ -367,3 +367,32 @@ def test_fused_zernike_masks_limits_and_liveness():
         for i in range(20):
             tran.transform(r, 1e-3, 0, 0, 0, 0, 1e-4)
     assert rec.launches == 2 and rec.fused_ops == 21
+
+
+def test_fused_zernike_with_masks_splits_instead_of_fusing():
+    """ind= masks and a Zernike trace do not share a program (register budget): the block still gives the
+    stand-alone results, with more launches."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    ro, ao = cases.noll_orders(21)
+    coeff = np.random.default_rng(4).normal(0, 1e-3, 21)
+    coeff[0] = 0.
+    c = _zern_bundle(4000, 10)
+    ind = np.random.default_rng(5).random(4000) < .5
+    a, b = dev_rays(c), dev_rays(c)
+
+    def chain(r):
+        tran.transform(r, .1, 0, 0, 0, 0, 1e-3, ind=ind)
+        surf.zernsurf(r, coeff, 50., rorder=ro, aorder=ao)
+        tran.reflect(r, ind=ind)
+        surf.flat(r)
+
+    chain(a)
+    with pxf.fused() as rec:
+        chain(b)
+    assert rec.launches >= 2
+    # (21 terms: the stand-alone launch uses the order-5 instantiation, the program the order-7 one --
+    # same arithmetic, roundings of the two may differ in the last bit)
+    for k, u, v in zip(ALLCOLS, a, b):
+        assert np.abs(u.cpu().numpy() - v.cpu().numpy()).max() <= 1e-12, k
