@@ -469,3 +469,44 @@ def test_zernike_every_radial_order(port, nmax):
     t = to_dev(c2)
     native.zernsurf.zernphase(*[t[k] for k in ALLCOLS], coeff, ro, ao, 50., 1e-3)
     check(to_host(t), want, "zernphase")
+
+
+def test_legsurf_and_conicplus_parameter_ranges(port):
+    """The host-folded tables of legSurf (orders 0..12, up to 48 terms) and conicplus (1..16 even
+    polynomial coefficients) over their whole supported ranges: bit for bit against the oracle, and the
+    documented refusals beyond them."""
+    from pyxfocus_amd import _lib, native
+    base = {name: (fn, cols, args) for name, fn, cols, args in cases.cases(num=400, seed=5)}
+    rng = np.random.default_rng(12)
+    fn, cols, args = base["legsurf"]
+    for nc, omax in ((1, 0), (3, 1), (10, 4), (25, 8), (48, 12)):
+        coeff = rng.normal(0, .1, nc)
+        xo = rng.integers(0, omax + 1, nc).astype(np.int32)
+        yo = rng.integers(0, omax + 1, nc).astype(np.int32)
+        xo[-1] = omax
+        a = tuple(args[:3]) + (coeff, xo, yo)
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, a)
+        t = to_dev(cols)
+        call_gpu(fn, t, a)
+        got = to_host(t)
+        for k in ALLCOLS:
+            assert bits_equal(got[k], want[k]).all(), ("legsurf", nc, omax, k)
+    t = to_dev(cols)
+    with pytest.raises(_lib.PxfError):
+        call_gpu(fn, t, tuple(args[:3]) + (np.ones(49), np.zeros(49, np.int32), np.zeros(49, np.int32)))
+    with pytest.raises(_lib.PxfError):
+        call_gpu(fn, t, tuple(args[:3]) + (np.ones(2), np.array([13, 0], np.int32), np.zeros(2, np.int32)))
+    fn, cols, args = base["conicplus"]
+    for npc in (1, 2, 5, 9, 16):
+        p = rng.normal(0, 1., npc) * 10. ** (-6. - 4. * np.arange(npc))
+        a = tuple(args[:2]) + (p,)
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, a)
+        t = to_dev(cols)
+        call_gpu(fn, t, a)
+        got = to_host(t)
+        for k in ALLCOLS:
+            assert bits_equal(got[k], want[k]).all(), ("conicplus", npc, k)
+    with pytest.raises(_lib.PxfError):
+        call_gpu(fn, to_dev(cols), tuple(args[:2]) + (np.ones(17) * 1e-30,))
