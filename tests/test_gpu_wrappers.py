@@ -920,3 +920,35 @@ def test_catalogue_lenses_expand_to_the_reference_sequences():
             expect(b, rev)
             same(a, b)
     assert lenses.AC508_250.__name__ == "AC508_250" and "AC508" in lenses.AC508_250.__doc__
+
+
+@pytest.mark.parametrize("nmax", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+def test_zernconic_every_order_lands_on_its_surface(nmax):
+    """Each zernconic instantiation (orders 2, 4, 6, 8 unrolled; 10 by run-time loops): the traced
+    points satisfy  z = conic sag + Zernike sum  (the sum from the oracle's zernset) and stay on their rays."""
+    import pyxfocus_amd.surfaces as surf
+    from oracle import api, cases
+    port = api.load_port()
+    rng = np.random.default_rng(300 + nmax)
+    n = 3000
+    R, K, rad = 2000., -.8, 60.
+    c = cases._randrays(rng, n, nsign=-1.)
+    c["x"] = rng.uniform(-40, 40, n); c["y"] = rng.uniform(-40, 40, n); c["z"] = rng.uniform(20, 30, n)
+    c["l"] *= .05; c["m"] *= .05
+    c["n"] = -np.sqrt(1 - c["l"] ** 2 - c["m"] ** 2)
+    nterms = (nmax + 1) * (nmax + 2) // 2
+    ro, ao = cases.noll_orders(nterms)
+    ro, ao = np.asarray(ro, np.int32), np.asarray(ao, np.int32)
+    coeff = rng.normal(0, 2e-3, nterms) / (1 + ro)
+    coeff[0] = 0.
+    rays = [dev(c[k]) for k in ALLCOLS]
+    surf.zernconic(rays, R, K, coeff, rad, rorder=ro, aorder=ao)
+    x, y, z = [rays[k].cpu().numpy() for k in (1, 2, 3)]
+    cc = 1. / R
+    for i in rng.choice(n, 150, replace=False):
+        rho, th = math.hypot(x[i], y[i]), math.atan2(y[i], x[i])
+        zv, _, _ = port.zernsurf.zernset(rho / rad, th, ro, ao)
+        sag = cc * rho ** 2 / (1 + math.sqrt(1 - (K + 1) * cc ** 2 * rho ** 2)) + float(np.dot(coeff, zv))
+        assert abs(z[i] - sag) < 1e-9, (nmax, i, z[i] - sag)
+    t = (z - c["z"]) / c["n"]
+    assert np.abs(c["x"] + c["l"] * t - x).max() < 1e-9 and np.abs(c["y"] + c["m"] * t - y).max() < 1e-9
