@@ -400,16 +400,7 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
         const char *e = getenv("PXF_PROGRAM_V");
         force_v = e ? atoi(e) : 0;
     }
-    int64_t nvec4 = 0;
-    if (aligned && force_v == 4 && !anymask) {   // experimental: 4 rays per thread
-        nvec4 = num / 4;
-        if (nvec4 > 0) {
-            if (nt) hipLaunchKernelGGL((program_kernel<4, true, false>), dim3(grid_for(nvec4)), dim3(kBlock), 0, s, c, (int64_t)0, nvec4, pg);
-            else hipLaunchKernelGGL((program_kernel<4, false, false>), dim3(grid_for(nvec4)), dim3(kBlock), 0, s, c, (int64_t)0, nvec4, pg);
-        }
-    }
-    const int64_t done4 = nvec4 * 4;
-    const int64_t nvec2 = (aligned && force_v != 1) ? (num - done4) / 2 : 0;
+    const int64_t nvec2 = (aligned && force_v != 1) ? num / 2 : 0;
 #define PXF_PLAUNCH(V, T, A, FIRST, NVEC)                                                                   \
     hipLaunchKernelGGL((program_kernel<V, T, A>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg)
 #define PXF_PLAUNCH_V(V, FIRST, NVEC)                      \
@@ -422,8 +413,8 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
             else PXF_PLAUNCH(V, false, false, FIRST, NVEC);     \
         }                                                  \
     } while (0)
-    if (nvec2 > 0) PXF_PLAUNCH_V(2, done4 / 2, nvec2);
-    const int64_t done = done4 + nvec2 * 2;
+    if (nvec2 > 0) PXF_PLAUNCH_V(2, (int64_t)0, nvec2);
+    const int64_t done = nvec2 * 2;
     if (done < num) PXF_PLAUNCH_V(1, done, num - done);
 #undef PXF_PLAUNCH_V
 #undef PXF_PLAUNCH

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B the fused program kernel: rays per thread.
-for v in 0 4 1; do
+for v in 0 1; do
   echo "== PXF_PROGRAM_V=$v"
   PXF_PROGRAM_V=$v timeout -k 10 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline | python3 -c "
 import json,sys
