@@ -466,7 +466,8 @@ int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total,
 #define PXF_OP_REFRACT 22      /* a: n1, n2 */
 #define PXF_OP_TRACEZERN 23    /* a: rad      ; aux = (const double *)&pxf_zern_args_t on the HOST */
 #define PXF_OP_TRACEZERNOPD 24 /* a: rad, nr  ; aux as above.  At most ONE Zernike operation per program, */
-                               /* such a program holds at most PXF_PROGRAM_MAX_OPS_ZERN operations, none of them masked */
+                               /* such a program holds at most PXF_PROGRAM_MAX_OPS_ZERN operations, unmasked, out of FLAT[OPD], */
+                               /* [I]TRANSFORM, REFLECT (PXF_ERANGE otherwise: run the trace as its own launch) */
 #define PXF_PROGRAM_MAX_OPS 32
 #define PXF_PROGRAM_MAX_OPS_ZERN 16
 #define PXF_PROGRAM_ZERN_MAX_ORDER 7 /* highest radial order of a FUSED Zernike trace (PXF_ERANGE above) */

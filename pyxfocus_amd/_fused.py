@@ -48,6 +48,8 @@ SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5,
 MAX_OPS = 32
 MAX_OPS_ZERN = 16      # PXF_PROGRAM_MAX_OPS_ZERN: a program around a Zernike trace
 ZERN_MAX_ORDER = 7     # PXF_PROGRAM_ZERN_MAX_ORDER: higher radial orders run as their own launch
+# what a program around a Zernike trace may hold besides the trace (pxf_program_zern.hip: zprog_supported)
+ZERN_COMPANIONS = {1, 2, 8, 9, 10}     # flat, flatopd, transform, itransform, reflect
 ZERN_CODES = {"pxf_tracezern": 23, "pxf_tracezernopd": 24}
 ZERN_SLOTS = {"pxf_tracezern": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_tracezernopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)}
 
@@ -105,8 +107,8 @@ class _Recorder:
         """Record one call; False if it cannot join the pending program (caller flushes and retries)."""
         if name not in OPCODES or len(self.ops) >= (MAX_OPS_ZERN if self.has_zern else MAX_OPS):
             return False
-        if self.has_zern and mask is not None:       # no ind= masks in a program around a Zernike trace
-            return False
+        if self.has_zern and (mask is not None or OPCODES[name] not in ZERN_COMPANIONS):
+            return False                              # no ind= masks / heavy operations around a Zernike trace
         ok, aux = self._bind(cols, SLOTS[name])
         if not ok:
             return False
@@ -123,7 +125,9 @@ class _Recorder:
     def try_add_zern(self, name, cols, tables, rad, nr, mask):
         """Record a tracezern[opd] call.  `tables` = (coeff, rorder, aorder) host arrays and their ctypes
         pointers; one Zernike operation per program, and such a program holds at most 16 operations."""
-        if self.has_zern or len(self.ops) >= MAX_OPS_ZERN or mask is not None or any(o.mask for o in self.ops):
+        if self.has_zern or len(self.ops) >= MAX_OPS_ZERN or mask is not None:
+            return False
+        if any(o.mask or o.code not in ZERN_COMPANIONS for o in self.ops):
             return False
         if len(tables[1]) and int(tables[1].max()) > ZERN_MAX_ORDER:
             return False

@@ -15,7 +15,10 @@
 namespace pxf {
 
 #ifndef PXF_ZPROG_WAVES
-#define PXF_ZPROG_WAVES 2
+#define PXF_ZPROG_WAVES 3
+#endif
+#ifndef PXF_ZPROG_HLDS
+#define PXF_ZPROG_HLDS false
 #endif
 constexpr int kMaxOpsZ = PXF_PROGRAM_MAX_OPS_ZERN;
 constexpr int kZernFusedMaxN = PXF_PROGRAM_ZERN_MAX_ORDER;
@@ -26,15 +29,42 @@ struct ProgramZ {  // a Program cut to the operation count a Zernike program may
     ProgOp op[kMaxOpsZ];
 };
 
-static_assert(sizeof(ProgramZ) + sizeof(ZernOp<kZernFusedMaxN, false>) + sizeof(Cols) + 64 <= 4096,
+static_assert(sizeof(ProgramZ) + sizeof(ZernOp<kZernFusedMaxN, false, PXF_ZPROG_HLDS>) + sizeof(Cols) + 64 <= 4096,
               "program + Zernike table must fit the kernel-argument segment");
 
-// (two waves per SIMD for every order: three, as the stand-alone Zernike kernel asks for n <= 7, costs 340
-// bytes of spills with the interpreter's other operations in the kernel; ONE lets the compiler use AGPRs
-// as spill space, and the NMAX = 15 instantiation built that way returned 1/rad in the x column)
+// (three waves per SIMD like the stand-alone order-7 kernel: 168 registers, eight of them spilled.  With
+// the library's full interpreter step in the kernel the same request cost 340 bytes of spills and two
+// waves were faster; with the lean step it is 5.4 ms for config 4 against 6.8 ms at two waves.)
+// The operations a Zernike program may hold besides the trace itself: the frame changes, reflect, flat.
+// The full interpreter step (pxf_program.h exec_op) inlines every Op of the library; its register and
+// scalar footprint on top of the Zernike evaluation pushed this kernel to two waves per SIMD with spills.
+__host__ __device__ constexpr bool zprog_supported(int code)
+{
+    return code == PXF_OP_FLAT || code == PXF_OP_FLATOPD || code == PXF_OP_TRANSFORM || code == PXF_OP_ITRANSFORM ||
+           code == PXF_OP_REFLECT || code == PXF_OP_TRACEZERN || code == PXF_OP_TRACEZERNOPD;
+}
+
+template <int V>
+__device__ __forceinline__ void exec_op_lite(int code, int flags, const double *__restrict__ P, Ray (&r)[V],
+                                             const bool (&sel)[V])
+{
+    switch (code) {
+        case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
+        case PXF_OP_FLATOPD: run_op(FlatOp<true>{P[0]}, r, sel); break;
+        case PXF_OP_TRANSFORM:
+            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            break;
+        case PXF_OP_ITRANSFORM:
+            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            break;
+        case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
+        default: break;
+    }
+}
+
 template <int NMAX, bool NT, bool ANYMASK>
 __global__ __launch_bounds__(kBlock, PXF_ZPROG_WAVES) void program_zern_kernel(Cols c, int64_t num, ProgramZ pg,
-                                                                                      ZernOp<NMAX, false> zop, int iz)
+                                                                                      ZernOp<NMAX, false, PXF_ZPROG_HLDS> zop, int iz)
 {
     constexpr int V = 1;
     zop.prologue();  // Zernike table -> LDS (contains the barrier: before any thread may exit)
@@ -65,7 +95,7 @@ __global__ __launch_bounds__(kBlock, PXF_ZPROG_WAVES) void program_zern_kernel(C
                 zop.template apply<V>(r, sel, wm);
                 if (!zop.has_opd) r[0].c[OPD] = opd_in;
             } else {
-                exec_op<V, NT>(o.code, o.flags, o.p, o.aux, vv, r, sel);
+                exec_op_lite<V>(o.code, o.flags, o.p, r, sel);
             }
             if (masked && !sel[0]) r[0] = keep[0];  // unselected rays keep every register
         }
@@ -84,7 +114,7 @@ template <int NMAX>
 static int launch_zern_nmax(const ProgramZ &pz, int iz, const ZernTab &tab, const Cols &c, int64_t num,
                             pxf_stream_t stream)
 {
-    ZernOp<NMAX, false> zop{};
+    ZernOp<NMAX, false, PXF_ZPROG_HLDS> zop{};
     for (int i = 0; i < zern_npairs(NMAX); i++) zop.tab_arg[i] = tab.a[i];
     zop.rad = pz.op[iz].p[0];
     zop.nr = pz.op[iz].p[1];
@@ -95,7 +125,7 @@ static int launch_zern_nmax(const ProgramZ &pz, int iz, const ZernTab &tab, cons
     // push this kernel deep into register spills (46 vector + 90 scalar registers) -- the caller runs
     // such a sequence as separate launches
     for (int i = 0; i < pz.nops; i++)
-        if (pz.op[i].mask != nullptr) return PXF_ERANGE;
+        if (pz.op[i].mask != nullptr || !zprog_supported(pz.op[i].code)) return PXF_ERANGE;
     if (use_nt(num))
         hipLaunchKernelGGL((program_zern_kernel<NMAX, true, false>), dim3(g), dim3(kBlock), 0, s, c, num, pz, zop, iz);
     else

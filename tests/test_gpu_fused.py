@@ -396,3 +396,29 @@ def test_fused_zernike_with_masks_splits_instead_of_fusing():
     # same arithmetic, roundings of the two may differ in the last bit)
     for k, u, v in zip(ALLCOLS, a, b):
         assert np.abs(u.cpu().numpy() - v.cpu().numpy()).max() <= 1e-12, k
+
+
+def test_fused_zernike_with_a_heavy_neighbour_splits():
+    """Only frame changes, reflect and flat share a program with a Zernike trace; a Wolter surface next
+    to it goes into its own program -- same results."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    ro, ao = cases.noll_orders(36)
+    coeff = np.random.default_rng(6).normal(0, 1e-3, 36)
+    coeff[0] = 0.
+    c = _zern_bundle(4000, 12)
+    a, b = dev_rays(c), dev_rays(c)
+
+    def chain(r):
+        surf.zernsurf(r, coeff, 50., rorder=ro, aorder=ao)
+        tran.reflect(r)
+        surf.conic(r, 5000., -1.)
+        tran.reflect(r)
+        surf.flat(r)
+
+    chain(a)
+    with pxf.fused() as rec:
+        chain(b)
+    assert rec.launches == 2 and rec.fused_ops == 5
+    same(a, b)

@@ -23,8 +23,7 @@ VGPR_SPILL_ALLOWED = {
     "pxf::ZernOpSel<7,": 8,          # the 36-term kernel at three waves per SIMD
     "pxf::ZernOpSel<8,": 4,
     "pxf::ZernOpSel<6,": 8, "pxf::ZernOpSel<5,": 8,
-    "pxf::program_zern_kernel<7,": 10,
-    "pxf::program_zern_kernel<4,": 10,
+    "pxf::program_zern_kernel<7,": 8,
 }
 
 
