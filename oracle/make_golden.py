@@ -16,9 +16,19 @@ and the outputs the reference produced for them.  No reference source text is st
                      bookkeeping, applyT/applyTPos, `ind` handling, vignette, radgrat dispatch.
   sources.npz        the reference's own sources.py under fixed np.random seeds.
 
-analyses.py / surfaces.py are NOT importable here (they import the un-vendored `utilities`
-package and astropy); their three-line wrappers/reductions are restated from the text and are
-pinned only through the native entry points they call -- stated in DESIGN.md.
+  analyses.npz       the reference's own analyses.py and surfaces.py (focus*) and
+                     transformations.steerX/Y run on focal bundles: centroid, rms*, rho, rhocdf, hpd
+                     (weighted and not), hpdY, analytic*Plane, indAngle/grazeAngle, measureOPD,
+                     rmsPoint, focusI/X/Y, steerX/Y.  analyses.py imports the un-vendored
+                     `utilities` package and astropy at module level (analyses.py:6-13) for
+                     functions OUTSIDE this set; those imports are satisfied by EMPTY module
+                     objects whose attributes raise when touched, so nothing but the reference's
+                     own NumPy code can have produced a recorded number.
+  config5.npz        a small Arcus-style multi-shell trace (sector.py:540-757 call shape) through
+                     the reference's own surfaces.py / transformations.py / analyses.py wrappers
+                     over the compiled Fortran: per-shell SPO pair, grating stage, focusY.
+
+Usage: make_golden.py [--only legacy|analyses|config5[,...]]   (legacy = the seven files above config5/analyses)
 """
 import hashlib
 import importlib.util
@@ -63,14 +73,192 @@ def shim_reference_python(ref):
     return tran, src
 
 
+class _Absent(types.ModuleType):
+    """Stand-in for a module the reference imports but this image lacks (`utilities.*`, astropy).
+    It has NO behaviour: any attribute access raises, so a recorded value cannot depend on it."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        raise RuntimeError("reference code touched %s.%s, which is absent from this image" % (self.__name__, name))
+
+
+def _untouchable(modname, name):
+    def f(*a, **k):
+        raise RuntimeError("reference code called %s.%s, which is absent from this image" % (modname, name))
+    return f
+
+
+def shim_reference_analyses(ref):
+    """Import the reference's own analyses.py and surfaces.py by path.  Needs shim_reference_python
+    first.  PyXFocus.{surfacesf,woltsurf,zernsurf,reconstruct} -> the compiled Fortran adapters;
+    PyXFocus.conicsolve -> the reference's file; un-vendored third-party modules -> _Absent."""
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    for name in ("utilities", "utilities.imaging", "utilities.imaging.man", "utilities.imaging.zernikemod",
+                 "astropy", "astropy.io", "astropy.io.fits", "PyXFocus.specialfunctions"):
+        if name not in sys.modules:
+            m = _Absent(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    for name, names in (("utilities.imaging.fitting", ("circle", "circleMerit")),
+                        ("utilities.imaging.analysis", ("ptov", "rms"))):
+        m = types.ModuleType(name)                 # `from X import a, b` needs the names to exist
+        for n in names:
+            setattr(m, n, _untouchable(name, n))
+        sys.modules[name] = m
+    sys.modules["utilities"].imaging = sys.modules["utilities.imaging"]
+    for sub in ("man", "zernikemod", "fitting", "analysis"):
+        object.__setattr__(sys.modules["utilities.imaging"], sub, sys.modules["utilities.imaging." + sub])
+    object.__setattr__(sys.modules["astropy"], "io", sys.modules["astropy.io"])
+    object.__setattr__(sys.modules["astropy.io"], "fits", sys.modules["astropy.io.fits"])
+    pkg = sys.modules["PyXFocus"]
+    for sub in ("surfacesf", "woltsurf", "zernsurf", "reconstruct"):
+        m = types.ModuleType("PyXFocus." + sub)
+        for k, v in vars(getattr(ref, sub)).items():
+            setattr(m, k, v)
+        sys.modules["PyXFocus." + sub] = m
+        setattr(pkg, sub, m)
+    pkg.specialfunctions = sys.modules["PyXFocus.specialfunctions"]
+    pkg.transformations = sys.modules["PyXFocus.transformations"]
+    pkg.conicsolve = _load_by_path("PyXFocus.conicsolve", os.path.join(REF, "conicsolve.py"))
+    anal = _load_by_path("PyXFocus.analyses", os.path.join(REF, "analyses.py"))
+    pkg.analyses = anal
+    surf = _load_by_path("PyXFocus.surfaces", os.path.join(REF, "surfaces.py"))
+    pkg.surfaces = surf
+    return anal, surf
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def focal_bundles(ref):
+    """Two focal-plane bundles for the analyses goldens: (a) the config-2 chain of chain_config2.npz
+    stopped 3 mm short of focus (a finite, ring-shaped spot), (b) a random converging bundle with
+    wide direction spread and non-trivial normals.  Dict of ten columns each."""
+    rng = np.random.default_rng(2)
+    rin, rout = cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR)
+    a = cases.annulus_rays(rng, 4096, rin, rout, 0.)
+    cases.chain_config2(ref, a)
+    nine = [a[k] for k in "x y z l m n ux uy uz".split()]
+    ref.transformationsf.transform(*nine, 0., 0., -3., 0., 0., 0.)
+    ref.surfacesf.flat(*nine)
+    rng = np.random.default_rng(9)
+    b = cases._randrays(rng, 3001, nsign=-1.)
+    b["x"], b["y"] = rng.normal(1.5, .8, 3001), rng.normal(-.7, 2.1, 3001)
+    b["z"] = rng.normal(0., .01, 3001)
+    b["opd"] = rng.uniform(0., 1., 3001)
+    return {"ring": a, "blob": b}
+
+
+def gold_analyses(ref, tran, anal, surf):
+    """The reference's own analyses.py (:16-187, :231-244), surfaces.focus* (:502-519) and
+    transformations.steerX/Y (:79-89) on the bundles of focal_bundles()."""
+    blob = {}
+    for tag, c in focal_bundles(ref).items():
+        rays = [c[k] for k in cases.ALLCOLS]
+        n = len(rays[1])
+        rng = np.random.default_rng(31)
+        wts = {"none": None, "smooth": 1. + .5 * np.sin(np.arange(n) * .37), "heavy": rng.pareto(1.5, n) + .01}
+        for k, v in zip(cases.ALLCOLS, rays):
+            blob["%s/in/%s" % (tag, k)] = v.copy()
+        for wtag, w in wts.items():
+            pre = "%s/%s/" % (tag, wtag)
+            if w is not None:
+                blob[pre + "w"] = w
+            blob[pre + "centroid"] = np.array(anal.centroid(rays, weights=w))
+            blob[pre + "rmsCentroid"] = np.array(anal.rmsCentroid(rays, weights=w))
+            blob[pre + "rmsX"] = np.array(anal.rmsX(rays, weights=w))
+            blob[pre + "rmsY"] = np.array(anal.rmsY(rays, weights=w))
+            blob[pre + "rmsPoint"] = np.array(anal.rmsPoint(rays, [.1, -.2, .3], weights=w))
+            blob[pre + "rho_cent"] = anal.rho(rays, weights=w, cent=True)
+            blob[pre + "hpd"] = np.array(anal.hpd(rays, weights=w))
+            blob[pre + "hpdY"] = np.array(anal.hpdY(rays, weights=w))
+            r, cdf = anal.rhocdf(rays, weights=w)
+            blob[pre + "rhocdf_r"], blob[pre + "rhocdf_cdf"] = r, cdf
+            blob[pre + "analyticImagePlane"] = np.array(anal.analyticImagePlane(rays, weights=w))
+            blob[pre + "analyticXPlane"] = np.array(anal.analyticXPlane(rays, weights=w))
+            blob[pre + "analyticYPlane"] = np.array(anal.analyticYPlane(rays, weights=w))
+            for fname in ("focusI", "focusX", "focusY"):
+                rr = tran.copy_rays(rays)
+                coords = tran.newCoords()
+                dz = getattr(surf, fname)(rr, weights=w, coords=coords)
+                blob[pre + fname + "/dz"] = np.array(dz)
+                blob[pre + fname + "/coords"] = np.array(coords)
+                for k, v in zip(cases.ALLCOLS, rr):
+                    if k in "xy":                   # flat leaves z = 0, u = (0,0,1), direction unchanged
+                        blob[pre + fname + "/out/" + k] = v
+                assert not rr[3].any() and (rr[9] == 1).all() and all(np.array_equal(rr[j], rays[j]) for j in (4, 5, 6))
+        blob[tag + "/rho_origin"] = anal.rho(rays)
+        blob[tag + "/measureOPD"] = anal.measureOPD(rays, [.1, -.2, .3])
+        blob[tag + "/measureOPD_ray"] = anal.measureOPD(rays, [r[7] for r in rays])
+        blob[tag + "/rmsPoint_ray"] = np.array(anal.rmsPoint(rays, [r[7] for r in rays]))
+        blob[tag + "/indAngle"] = anal.indAngle(rays)
+        blob[tag + "/grazeAngle"] = anal.grazeAngle(rays)
+        sel = np.random.default_rng(5).random(n) < .3
+        blob[tag + "/sel"] = sel
+        blob[tag + "/indAngle_sel"] = anal.indAngle(rays, ind=sel)
+        blob[tag + "/grazeAngle_sel"] = anal.grazeAngle(rays, ind=sel)
+        blob[tag + "/indAngle_normal"] = anal.indAngle(rays, normal=[0., .6, .8])
+        blob[tag + "/indAngle_normal_sel"] = anal.indAngle(rays, ind=sel, normal=[0., .6, .8])
+        for fname in ("steerX", "steerY"):
+            rr = tran.copy_rays(rays)
+            coords = tran.newCoords()
+            getattr(tran, fname)(rr, coords=coords)
+            blob["%s/%s/coords" % (tag, fname)] = np.array(coords)
+            for k, v in zip(cases.ALLCOLS, rr):
+                blob["%s/%s/out/%s" % (tag, fname, k)] = v
+    np.savez_compressed(os.path.join(OUT, "analyses.npz"), **blob)
+    print("analyses:", len(blob), "arrays")
+
+
+CONFIG5_GOLD = {"N": 16, "shell_stride": 8, "modules_per_row": 2, "seed": 0, "order": -3, "wave": 2.4}
+
+
+def gold_config5(tran, src, anal, surf):
+    """examples/arcus_sector.py (the call shapes of the reference's examples/arcus/sector.py) bound
+    to the reference's OWN sources / surfaces / transformations / analyses modules over the
+    compiled Fortran, NumPy columns.  Records the focal bundle, weights, focusY shift, coords."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import arcus_sector as A
+    a = A.Api(src, surf, tran, anal, np)
+    g = CONFIG5_GOLD
+    np.random.seed(g["seed"])
+    out = A.traceArcus(a, g["N"], order=g["order"], wave=g["wave"], shell_stride=g["shell_stride"],
+                       modules_per_row=g["modules_per_row"])
+    blob = {"par/" + k: np.array(v) for k, v in g.items()}
+    for k, v in zip(cases.ALLCOLS, out["rays"]):
+        blob["out/" + k] = v
+    blob["weights"] = out["weights"]
+    blob["dz"] = np.array(out["dz"])
+    blob["grating_rows"] = np.array(out["grating_rows"])
+    blob["hubdist"], blob["angle"] = np.array(out["hubdist"]), np.array(out["angle"])
+    blob["coords"] = np.array(out["coords"])
+    r, w = out["rays"], out["weights"]
+    blob["centroid_w"] = np.array(anal.centroid(r, weights=w))
+    blob["hpd_w"] = np.array(anal.hpd(r, weights=w))
+    blob["rmsY_w"] = np.array(anal.rmsY(r, weights=w))
+    np.savez_compressed(os.path.join(OUT, "config5.npz"), **blob)
+    print("config5: %d rays, %d grating rows, focusY dz = %.9f, line centroid (%.6f, %.6f)" % (
+        len(r[1]), out["grating_rows"], out["dz"], *blob["centroid_w"]))
+
+
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5")
+    only = [t for t in ap.parse_args().only.split(",") if t]
     os.makedirs(OUT, exist_ok=True)
     ref = api.load_ref()
     tran, src = shim_reference_python(ref)
+    if not only or "analyses" in only or "config5" in only:
+        anal, surf = shim_reference_analyses(ref)
+        if not only or "analyses" in only:
+            gold_analyses(ref, tran, anal, surf)
+        if not only or "config5" in only:
+            gold_config5(tran, src, anal, surf)
+    if only and "legacy" not in only:
+        return
 
     # ---- native cases ------------------------------------------------------------------
     blob = {}

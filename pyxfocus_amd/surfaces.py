@@ -334,24 +334,29 @@ def ellipsoidSecondaryLL(rays, R0, F, S, psi, zmax, zmin, dphi, coeff, axial, az
     return
 
 
-def focus(rays, fn, weights=None, nr=None, coords=None):
-    """Two passes of: analytic best-focus shift -> move frame -> flat (surfaces.py:502-510)."""
-    dz1 = fn(rays, weights=weights)
+def focus(rays, fn, weights=None, nr=None, coords=None, group=None):
+    """Two passes of: analytic best-focus shift -> move frame -> flat (surfaces.py:502-510).
+
+    ``group=`` (a torch.distributed process group, or True for the default one) is an addition for
+    ray-sharded runs: `rays` is then this rank's shard and the moments behind `fn` are all-reduced,
+    so every rank moves its frame by the SAME dz (the reference has one bundle, hence one shift)."""
+    kw = {} if group is None else {"group": group}
+    dz1 = fn(rays, weights=weights, **kw)
     tran.transform(rays, 0, 0, dz1, 0, 0, 0, coords=coords)
     flat(rays, nr=nr)
-    dz2 = fn(rays, weights=weights)
+    dz2 = fn(rays, weights=weights, **kw)
     tran.transform(rays, 0, 0, dz2, 0, 0, 0, coords=coords)
     flat(rays, nr=nr)
     return dz1 + dz2
 
 
-def focusY(rays, weights=None, nr=None, coords=None):
-    return focus(rays, analyses.analyticYPlane, weights=weights, nr=nr, coords=coords)
+def focusY(rays, weights=None, nr=None, coords=None, group=None):
+    return focus(rays, analyses.analyticYPlane, weights=weights, nr=nr, coords=coords, group=group)
 
 
-def focusX(rays, weights=None, nr=None, coords=None):
-    return focus(rays, analyses.analyticXPlane, weights=weights, nr=nr, coords=coords)
+def focusX(rays, weights=None, nr=None, coords=None, group=None):
+    return focus(rays, analyses.analyticXPlane, weights=weights, nr=nr, coords=coords, group=group)
 
 
-def focusI(rays, weights=None, nr=None, coords=None):
-    return focus(rays, analyses.analyticImagePlane, weights=weights, nr=nr, coords=coords)
+def focusI(rays, weights=None, nr=None, coords=None, group=None):
+    return focus(rays, analyses.analyticImagePlane, weights=weights, nr=nr, coords=coords, group=group)

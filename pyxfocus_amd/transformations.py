@@ -113,23 +113,24 @@ def itransform(rays, dx, dy, dz, rx, ry, rz, coords=None, ind=None):
     return
 
 
-def _mean(col):
+def _mean(col, group=None):
     from . import analyses
-    s = analyses._moments([None, col, col], None, dirs=False)   # np.mean(col): S x / S 1
+    s = analyses._moments([None, col, col], None, dirs=False, group=group)   # np.mean(col): S x / S 1
     return s[1] / s[0]
 
 
-def steerY(rays, coords=None):
-    """Rotate reference frame for zero mean y tilt (transformations.py:79-83)"""
-    while abs(_mean(rays[5])) > 1e-6:
-        transform(rays, 0, 0, 0, -_mean(rays[5]), 0, 0, coords=coords)
+def steerY(rays, coords=None, group=None):
+    """Rotate reference frame for zero mean y tilt (transformations.py:79-83).
+    group= (ray-sharded runs): the mean is all-reduced, every rank applies the same rotations."""
+    while abs(_mean(rays[5], group)) > 1e-6:
+        transform(rays, 0, 0, 0, -_mean(rays[5], group), 0, 0, coords=coords)
     return
 
 
-def steerX(rays, coords=None):
-    """Rotate reference frame for zero mean x tilt (transformations.py:85-89)"""
-    while abs(_mean(rays[4])) > 1e-6:
-        transform(rays, 0, 0, 0, 0, -_mean(rays[4]), 0, coords=coords)
+def steerX(rays, coords=None, group=None):
+    """Rotate reference frame for zero mean x tilt (transformations.py:85-89); group= as steerY."""
+    while abs(_mean(rays[4], group)) > 1e-6:
+        transform(rays, 0, 0, 0, 0, -_mean(rays[4], group), 0, coords=coords)
     return
 
 
@@ -323,8 +324,14 @@ def applyT(rays, coords, inverse=False):
 
 def applyTPos(x, y, z, coords, inverse=False):
     """Apply transformation to list of points (transformations.py:282-289).  Returns a (3, N) tensor."""
-    fused.flush()
     i = 2 if inverse is True else 0
+    if not isinstance(x, torch.Tensor):
+        # a handful of host points (scalars or NumPy arrays, e.g. applyTPos(0,0,0,coords) to locate
+        # an origin): the reference's own product on the host, (3, N) ndarray
+        pos = np.array([np.ravel(np.asarray(v, dtype=float)) for v in (x, y, z)])
+        pos = np.vstack([pos, np.ones(pos.shape[1])])
+        return np.dot(np.asarray(coords[i + 1], dtype=float), pos)[:3]
+    fused.flush()
     num, dev = native._check_cols((x, y, z), "applyTPos")
     mpos, ppos = _m16(coords[i + 1])
     out = torch.empty((3, num), dtype=torch.float64, device=dev)

@@ -86,3 +86,44 @@ def test_shard_range_properties():
                 assert a[1] == b[0]
             sizes = [hi - lo for lo, hi in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _gather_worker(rank, world, port, counts, scratch, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyxfocus_amd import dist as pdist
+        lo = sum(counts[:rank])
+        base = torch.arange(lo, lo + counts[rank], dtype=torch.float64)
+        cols = [base, -2. * base, base + .5]
+        if rank == 1 and counts[rank] > 1:
+            cols[1] = torch.stack([cols[1], cols[1]], 1)[:, 0]         # a strided (non-contiguous) view
+        out = pdist.all_gather_focal(cols, scratch_bytes=scratch)
+        q.put((rank, [o.numpy() for o in out]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts,scratch", [
+    ((1000, 1000), None),            # equal shards: one collective per column, straight into place
+    ((1000, 37), None),              # uneven, one chunk
+    ((1000, 37), 24 * 64),           # uneven, 64-element chunks: 16 rounds per column, rank 1 runs dry early
+    ((0, 513), 24 * 100),            # an empty shard
+    ((0, 0), None),                  # nothing survived anywhere
+    ((5, 7, 6), 32 * 2),             # three ranks, 2-element chunks
+])
+def test_all_gather_focal_bounded_memory_paths(counts, scratch):
+    world = len(counts)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, counts, scratch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.arange(sum(counts), dtype=np.float64)
+    for rank, out in res:
+        assert np.array_equal(out[0], want) and np.array_equal(out[1], -2. * want) and np.array_equal(out[2], want + .5)

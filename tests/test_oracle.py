@@ -136,3 +136,78 @@ def test_wavefront_port_matches_reference_live(port, ref):
         a, b = cases.wavefront_run(port, case, criteria=1e-9, maxiter=50), cases.wavefront_run(ref, case, 1e-9, 50)
         for k in a:
             assert np.array_equal(a[k], b[k]), (case[0], k)
+
+
+# ---- the NumPy restatement of the wrapper layer (oracle/wrappers.py) vs the reference's OWN Python --------
+WTAGS = ("none", "smooth", "heavy")
+
+
+def analyses_golden_cases(g):
+    """(bundle tag, weight tag, ten input columns, weights or None) of tests/golden/analyses.npz."""
+    for tag in ("ring", "blob"):
+        rays = [g["%s/in/%s" % (tag, k)] for k in ALLCOLS]
+        for wt in WTAGS:
+            yield tag, wt, rays, (None if wt == "none" else g["%s/%s/w" % (tag, wt)])
+
+
+def test_wrappers_analyses_equal_reference_python(port, golden):
+    """analyses.py / surfaces.focus* / transformations.steer* restated in oracle/wrappers.py give the
+    numbers the reference's own modules gave (same NumPy, same operation order -> identical)."""
+    from oracle import wrappers
+    src, surf, tran, anal = wrappers.bind(port)
+    g = golden["analyses"]
+    for tag, wt, rays, w in analyses_golden_cases(g):
+        pre = "%s/%s/" % (tag, wt)
+        for name in ("centroid", "rmsCentroid", "rmsX", "rmsY", "hpd", "hpdY", "analyticImagePlane",
+                     "analyticXPlane", "analyticYPlane"):
+            got = np.array(getattr(anal, name)(rays, weights=w))
+            assert np.array_equal(got, g[pre + name]), (pre, name, got, g[pre + name])
+        assert np.array_equal(anal.rmsPoint(rays, [.1, -.2, .3], weights=w), g[pre + "rmsPoint"])
+        assert np.array_equal(anal.rho(rays, weights=w, cent=True), g[pre + "rho_cent"])
+        r, cdf = anal.rhocdf(rays, weights=w)
+        assert np.array_equal(r, g[pre + "rhocdf_r"]) and np.array_equal(cdf, g[pre + "rhocdf_cdf"])
+        for fname in ("focusI", "focusX", "focusY"):
+            rr, coords = tran.copy_rays(rays), tran.newCoords()
+            dz = getattr(surf, fname)(rr, weights=w, coords=coords)
+            assert dz == float(g[pre + fname + "/dz"]), (pre, fname)
+            assert np.array_equal(np.array(coords), g[pre + fname + "/coords"])
+            assert bits_equal(rr[1], g[pre + fname + "/out/x"]).all() and bits_equal(rr[2], g[pre + fname + "/out/y"]).all()
+    for tag in ("ring", "blob"):
+        rays = [g["%s/in/%s" % (tag, k)] for k in ALLCOLS]
+        sel = g[tag + "/sel"]
+        assert np.array_equal(anal.rho(rays), g[tag + "/rho_origin"])
+        assert np.array_equal(anal.measureOPD(rays, [.1, -.2, .3]), g[tag + "/measureOPD"])
+        assert np.array_equal(anal.measureOPD(rays, [r[7] for r in rays]), g[tag + "/measureOPD_ray"])
+        assert np.array_equal(anal.indAngle(rays), g[tag + "/indAngle"], equal_nan=True)
+        assert np.array_equal(anal.grazeAngle(rays), g[tag + "/grazeAngle"], equal_nan=True)
+        assert np.array_equal(anal.indAngle(rays, ind=sel), g[tag + "/indAngle_sel"], equal_nan=True)
+        assert np.array_equal(anal.grazeAngle(rays, ind=sel), g[tag + "/grazeAngle_sel"], equal_nan=True)
+        assert np.array_equal(anal.indAngle(rays, normal=[0., .6, .8]), g[tag + "/indAngle_normal"], equal_nan=True)
+        assert np.array_equal(anal.indAngle(rays, ind=sel, normal=[0., .6, .8]), g[tag + "/indAngle_normal_sel"],
+                              equal_nan=True)
+        for fname in ("steerX", "steerY"):
+            rr, coords = tran.copy_rays(rays), tran.newCoords()
+            getattr(tran, fname)(rr, coords=coords)
+            assert np.array_equal(np.array(coords), g["%s/%s/coords" % (tag, fname)])
+            for k, v in zip(ALLCOLS, rr):
+                assert bits_equal(v, g["%s/%s/out/%s" % (tag, fname, k)]).all(), (tag, fname, k)
+
+
+def test_wrappers_config5_equals_reference_python(port, golden):
+    """examples/arcus_sector.py on oracle/wrappers.py over the C restatement == the same driver on the
+    reference's own sources / surfaces / transformations / analyses over its compiled Fortran."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import arcus_sector as A
+    from oracle import wrappers
+    g = golden["config5"]
+    np.random.seed(int(g["par/seed"]))
+    out = A.traceArcus(A.Api(*wrappers.bind(port), np), int(g["par/N"]), order=int(g["par/order"]),
+                       wave=float(g["par/wave"]), shell_stride=int(g["par/shell_stride"]),
+                       modules_per_row=int(g["par/modules_per_row"]))
+    assert out["grating_rows"] == int(g["grating_rows"]) and out["dz"] == float(g["dz"])
+    assert np.array_equal(np.array(out["coords"]), g["coords"])
+    for k, v in zip(ALLCOLS, out["rays"]):
+        assert bits_equal(v, g["out/" + k]).all(), k
+    assert np.array_equal(out["weights"], g["weights"])
