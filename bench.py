@@ -13,16 +13,25 @@ would be different work): K+W bundles are generated on the device before the tim
 (8 GB each at 1e8 rays; 288 GB of HBM3E holds the default 12 with room to spare).  Inputs are
 therefore resident in HBM when timing starts; nothing is generated, copied or reduced inside it.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): rays shard by global index, each rank
-traces its own 1e8 rays (weak scaling), no collective in the data path.  After the timed region
-the ranks all-reduce the focal-plane moments and all-gather the focal (x,y) over RCCL/xGMI -- the
-one exchange the path has -- and report its time separately.
+`--gpus N` with N > 1: if the process was not started by torch.distributed.run (no WORLD_SIZE), it
+starts N ranks itself -- as a CHILD `python -m torch.distributed.run`, before this process touches
+the GPU -- and relays rank 0's line.  One rank per GPU over RCCL; rays shard by global index, each
+rank traces its own 1e8 rays (weak scaling), no collective in the data path.  After the timed region
+the ranks all-reduce the focal-plane moments and all-gather the focal (x,y) over RCCL/xGMI -- the one
+exchange the path has -- and report its time separately.  On a box with fewer GPUs than ranks the
+ranks share the GPU(s) over gloo: a REHEARSAL of the N>1 code path, flagged as such in the line.
+
+At N=1 the line also carries `configs`: BASELINE configs 3 (two-bounce + radial grating, 1e9 rays) and
+4 (36-term Zernike surface, 1e9 rays) measured the same way, each with its own roofline.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,40 +41,57 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-R0, Z0, PSI, LMIR = 220., 8400., 1., 100.
-BYTES = {"transform": 144, "wolterprimary": 96, "reflect": 72, "woltersecondary": 96, "flat": 96}
-CHAIN = ["transform", "wolterprimary", "reflect", "woltersecondary", "reflect", "flat"]
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+from tools import workloads as wl  # noqa: E402
+
+R0, Z0, PSI, LMIR = wl.R0, wl.Z0, wl.PSI, wl.LMIR
+HBM_PEAK_GBS = wl.HBM_PEAK_GBS
+ORDER = "opd x y z l m n ux uy uz".split()
 
 
-def chain_step(rays, tran, surf, ev=None):
-    """One pass of the hot path.  `ev`: optional list of 7 torch.cuda.Event to bracket each launch."""
-    def mark(i):
-        if ev is not None:
-            ev[i].record()
-    mark(0)
-    tran.transform(rays, 0, 0, -(Z0 + 2 * LMIR), 0, 0, 0)
-    mark(1)
-    surf.wolterprimary(rays, R0, Z0, PSI)
-    mark(2)
-    tran.reflect(rays)
-    mark(3)
-    surf.woltersecondary(rays, R0, Z0, PSI)
-    mark(4)
-    tran.reflect(rays)
-    mark(5)
-    surf.flat(rays)
-    mark(6)
+def csrc_hash():
+    """Identity of the kernel sources a PMC capture belongs to (profiles/pmc_*.json carry it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pyxfocus_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(gpu_chain, target_seconds=12.0):
-    """Reference Fortran (oracle/_ref, OpenMP build) -- or our C port if _ref did not travel --
-    timed on this box's host cores on a bounded sample of the same workload.  The first 1e5 rays of
-    the sample also go through the GPU path (`gpu_chain(cols, fused)`), and the two results are
-    compared: the checker's only other job in this file."""
-    from oracle import api, cases
-    # threads actually usable: the cgroup CPU quota (16 on a 1-GPU box), not the 256 visible cores;
-    # must be in the environment BEFORE the OpenMP runtime initialises
+def pmc_entry(fname, key, rays):
+    """A committed PMC figure (tools/pmc_collect.py) for `key` -- only if it was captured from THESE
+    kernel sources and at this launch size; otherwise None (never a stale number)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        ent = tj["kernels"].get(key)
+        if ent and tj.get("csrc_hash") == csrc_hash() and int(ent.get("rays", 0)) == int(rays):
+            return dict(ent, source=tj.get("source"), commit=tj.get("commit"))
+    except Exception:
+        pass
+    return None
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks as a child torch.distributed.run (this process has
+    not touched the GPU: device_count() does not initialise HIP) and exit with its code."""
+    ndev = torch.cuda.device_count()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    extra = []
+    if ndev < args.gpus:                       # rehearsal: ranks share GPUs, collectives over gloo
+        share = -(-args.gpus // max(ndev, 1))
+        extra = ["--backend", "gloo", "--pool-gb", str(args.pool_gb / share)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def host_cores():
+    """Threads actually usable: the cgroup CPU quota (16 on a 1-GPU box), not the visible cores."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -73,16 +99,29 @@ def cpu_baseline(gpu_chain, target_seconds=12.0):
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except Exception:
         pass
-    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or cores
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    kind, be = "port", None
+    return int(os.environ.get("OMP_NUM_THREADS", 0)) or cores
+
+
+def checker(omp):
+    """The CPU checker: the reference's own Fortran (oracle/_ref) if it travelled, else our C port."""
+    from oracle import api
     try:
-        if api.ref_available(omp=True):
-            be, kind = api.load_ref(omp=True), "reference"
+        if api.ref_available(omp=omp):
+            return api.load_ref(omp=omp), "reference"
     except OSError:
-        be = None
-    if be is None:
-        be = api.load_port(omp=True)
+        pass
+    return api.load_port(omp=omp), "port"
+
+
+def cpu_baseline(gpu_chain, target_seconds=12.0):
+    """Reference Fortran (oracle/_ref, OpenMP build) -- or our C port if _ref did not travel --
+    timed on this box's host cores on a bounded sample of the same workload.  The first 1e5 rays of
+    the sample also go through the GPU path (`gpu_chain(cols, fused)`), and the two results are
+    compared: the checker's only other job in this file."""
+    from oracle import cases
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)          # before the OpenMP runtime initialises
+    be, kind = checker(omp=True)
     n = 10_000_000
     rng = np.random.default_rng(0)
     rin, rout = cases.primrad(Z0), cases.primrad(Z0 + LMIR)
@@ -96,12 +135,11 @@ def cpu_baseline(gpu_chain, target_seconds=12.0):
         cases.chain_config2(be, c)
         spent += time.perf_counter() - t0
         reps += 1
-    # single-thread figure: the serial build of the same checker, 1e6-ray sample, ~3 s
-    one = None
+    one = None                                       # single-thread figure: serial build, 1e6 rays, ~3 s
     try:
-        be1 = api.load_ref(omp=False) if kind == "reference" else api.load_port(omp=False)
+        be1, _ = checker(omp=False)
         n1, r1, s1 = 1_000_000, 0, 0.0
-        while s1 < 3.0 and r1 < 1000:
+        while s1 < min(3.0, target_seconds / 4) and r1 < 1000:
             c1 = {k: v[:n1].copy() for k, v in src.items()}
             t0 = time.perf_counter()
             cases.chain_config2(be1, c1)
@@ -125,6 +163,179 @@ def cpu_baseline(gpu_chain, target_seconds=12.0):
             "one_thread_rays_per_s": one, "parity_vs_gpu": parity}
 
 
+class Marks:
+    """HIP events around every launch of a chain, on torch's current stream (= the stream the kernels
+    are launched on: native._stream)."""
+
+    def __init__(self, n):
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+
+    def __call__(self, i):
+        self.ev[i].record()
+
+    def ms(self):
+        return [self.ev[i].elapsed_time(self.ev[i + 1]) for i in range(len(self.ev) - 1)]
+
+
+def kernel_table(names_bytes, per_step_ms, n):
+    """Average per-launch durations -> [{launch, kernel, avg_ms, bytes_per_ray, GBps}]."""
+    out = []
+    for j, (name, nb) in enumerate(names_bytes):
+        avg = float(np.mean([ms[j] for ms in per_step_ms]))
+        out.append({"launch": j, "kernel": name, "avg_ms": avg, "bytes_per_ray": nb,
+                    "GBps": nb * n / (avg * 1e-3) / 1e9})
+    return out
+
+
+def parity_vs_checker(chain_np, chain_dev, make_cols, dev, tol_note):
+    """RMS ray-position error of the device chain vs the CPU checker on the same 1e5 seeded rays."""
+    from oracle import wrappers
+    be, kind = checker(omp=False)
+    osrc, osurf, otran, oanal = wrappers.bind(be)
+    cols = make_cols()
+    want = [c.copy() for c in cols]
+    chain_np(want, otran, osurf)
+    got = [torch.from_numpy(c.copy()).to(dev) for c in cols]
+    chain_dev(got)
+    got = [g.cpu().numpy() for g in got]
+    f = np.isfinite(want[1]) & np.isfinite(want[2]) & np.isfinite(want[3])
+    same_nan = bool(np.array_equal(f, np.isfinite(got[1]) & np.isfinite(got[2]) & np.isfinite(got[3])))
+    d2 = sum((got[j][f] - want[j][f]) ** 2 for j in (1, 2, 3))
+    return {"rays": len(cols[1]), "checker": kind, "valid_fraction": float(f.mean()), "same_failed_rays": same_nan,
+            "rms_pos_err_mm": float(np.sqrt(d2.mean())), "max_pos_err_mm": float(np.sqrt(d2.max())),
+            "bit_identical": bool(all(np.array_equal(g, w, equal_nan=True) for g, w in zip(got, want))),
+            "tolerance": tol_note}
+
+
+def bench_config3(n, steps, dev, pxf, sources, tran, surf, con):
+    """BASELINE config 3: config-2 chain + one radial grating stage, 12 launches, 1192 B/ray."""
+    rin, rout = float(con.primrad(Z0, R0, Z0)), float(con.primrad(Z0 + LMIR, R0, Z0))
+    fresh = lambda seed: sources.subannulus(rin, rout, 0.5, n, zhat=-1., rng="philox", seed=seed)
+    per, fms = [], []
+    for r in range(steps + 1):
+        rays = fresh(30 + r)
+        m = Marks(len(wl.CONFIG3))
+        wl.config3_chain(rays, tran, surf, m)
+        torch.cuda.synchronize()
+        if r:
+            per.append(m.ms())
+        if r == steps:
+            valid = float(torch.isfinite(rays[6]).double().mean())
+        del rays
+    for r in range(steps + 1):
+        rays = fresh(60 + r)
+        m = Marks(1)
+        m(0)
+        with pxf.fused():
+            wl.config3_chain(rays, tran, surf)
+        m(1)
+        torch.cuda.synchronize()
+        if r:
+            fms.append(m.ms()[0])
+        del rays
+    kern = kernel_table(wl.CONFIG3, per, n)
+    tot = sum(k["avg_ms"] for k in kern)
+    dom = max(kern, key=lambda k: k["avg_ms"])
+    f = float(np.mean(fms))
+
+    def cols():
+        rng = np.random.default_rng(33)
+        k = 100_000
+        rho = np.sqrt(rin ** 2 + rng.random(k) * (rout ** 2 - rin ** 2))
+        th = rng.random(k) * .5 - .25
+        z = np.zeros(k)
+        return [z.copy(), rho * np.cos(th), rho * np.sin(th), z.copy(), z.copy(), z.copy(), z - 1., z.copy(), z.copy(),
+                z.copy()]
+    par = parity_vs_checker(lambda r, t, s: wl.config3_chain(r, t, s), lambda r: wl.config3_chain(r, tran, surf),
+                            cols, dev, "bit-identical up to radgrat (1e-14 on cosines), then <1e-10 mm RMS")
+    return {"workload": "config3: %g rays subannulus -> config-2 chain -> transform -> flat -> reflect -> radgrat "
+                        "-> itransform -> flat (one radial grating, 160 nm at the hub distance, order 1, 2.4 nm)" % n,
+            "rays": n, "steps": steps, "launches_per_step": 12, "algorithmic_bytes_per_ray": wl.BYTES["config3"],
+            "ms_per_step": tot, "value": n / (tot * 1e-3), "unit": "rays/s", "valid_fraction": valid,
+            "chain_GBps": wl.BYTES["config3"] * n / (tot * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": dom["bytes_per_ray"] * n, "avg_launch_ms": dom["avg_ms"],
+                         "traffic": (pmc_entry("pmc_traffic.json", "config3:" + dom["kernel"], n) or {}).get("hbm_bytes_per_launch")},
+            "kernels": kern,
+            "fused": {"ms_per_step": f, "value": n / (f * 1e-3), "unit": "rays/s", "launches_per_step": 1,
+                      "algorithmic_bytes_per_ray": wl.FUSED_BYTES["config3"],
+                      "GBps": wl.FUSED_BYTES["config3"] * n / (f * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": wl.FUSED_BYTES["config3"] * n / (f * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "parity_vs_checker": par}
+
+
+def bench_config4(n, steps, dev, pxf, sources, tran, surf):
+    """BASELINE config 4: 36-term Zernike sag surface (rad 50), zernsurf -> reflect -> flat, 264 B/ray.
+    fp64-VALU-bound: reports the HBM fraction AND the fp64 rate against the 78.6 TF vector peak
+    (flops per ray from the SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 counters of profiles/pmc_flops.json)."""
+    from oracle import cases
+    par4 = wl.config4_setup(surf.zmodes)
+
+    def fresh(seed):
+        rays = sources.circularbeam(50., n, rng="philox", seed=seed)
+        wl.config4_prepare(rays)
+        return rays
+    per, fms = [], []
+    for r in range(steps + 1):
+        rays = fresh(40 + r)
+        m = Marks(3)
+        wl.config4_chain(rays, tran, surf, par4, m)
+        torch.cuda.synchronize()
+        if r:
+            per.append(m.ms())
+        if r == steps:
+            valid = float(torch.isfinite(rays[1]).double().mean())
+        del rays
+    for r in range(steps + 1):
+        rays = fresh(70 + r)
+        m = Marks(1)
+        m(0)
+        with pxf.fused():
+            wl.config4_chain(rays, tran, surf, par4)
+        m(1)
+        torch.cuda.synchronize()
+        if r:
+            fms.append(m.ms()[0])
+        del rays
+    kern = kernel_table(wl.CONFIG4, per, n)
+    tot = sum(k["avg_ms"] for k in kern)
+    z = kern[0]
+    f = float(np.mean(fms))
+    roof = {"bound": "fp64-valu", "kernel": "zernsurf", "hbm_achieved_GBps": z["GBps"], "hbm_peak_GBps": HBM_PEAK_GBS,
+            "hbm_frac": z["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": z["avg_ms"],
+            "algorithmic_bytes_per_launch": z["bytes_per_ray"] * n}
+    fl = pmc_entry("pmc_flops.json", "config4:zernsurf", n) or pmc_entry("pmc_flops.json", "config4:zernsurf", 10 ** 8)
+    if fl:
+        tf = fl["fp64_flops_per_ray"] * n / (z["avg_ms"] * 1e-3) / 1e12
+        roof.update({"achieved": tf, "peak": wl.FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / wl.FP64_VECTOR_PEAK_TFLOPS, "fp64_flops_per_ray": fl["fp64_flops_per_ray"],
+                     "flops_source": "%s @ %s" % (fl.get("source"), fl.get("commit"))})
+
+    def cols():
+        rng = np.random.default_rng(44)
+        k = 100_000
+        rho, th = np.sqrt(rng.random(k)) * 50., rng.random(k) * 2 * np.pi
+        z0 = np.zeros(k)
+        c = [z0.copy(), rho * np.cos(th), rho * np.sin(th), z0.copy(), z0.copy(), z0.copy(), z0.copy(), z0.copy(),
+             z0.copy(), z0.copy()]
+        wl.config4_prepare(c)
+        return c
+    opar = wl.config4_setup(cases.noll_orders)
+    par = parity_vs_checker(lambda r, t, s: wl.config4_chain(r, t, s, opar),
+                            lambda r: wl.config4_chain(r, tran, surf, par4), cols, dev,
+                            "tracezern is tolerance-parity (FMA, no libm): 2e-11 mm asserted in tests")
+    return {"workload": "config4: %g rays circularbeam(50) -> zernsurf(36 Noll terms ~N(0,1e-3) mm, rad 50) -> "
+                        "reflect -> flat" % n,
+            "rays": n, "steps": steps, "launches_per_step": 3, "algorithmic_bytes_per_ray": wl.BYTES["config4"],
+            "ms_per_step": tot, "value": n / (tot * 1e-3), "unit": "rays/s", "valid_fraction": valid,
+            "zernsurf_rays_per_s": n / (z["avg_ms"] * 1e-3), "roofline": roof, "kernels": kern,
+            "fused": {"ms_per_step": f, "value": n / (f * 1e-3), "unit": "rays/s", "launches_per_step": 1,
+                      "algorithmic_bytes_per_ray": wl.FUSED_BYTES["config4"],
+                      "GBps": wl.FUSED_BYTES["config4"] * n / (f * 1e-3) / 1e9},
+            "parity_vs_checker": par}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,15 +345,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--configs", default=None, help="extra BASELINE configs measured into `configs` "
+                    "(comma list of 3,4; default: both at N=1, none at N>1; '' for none)")
+    ap.add_argument("--config-rays", type=float, default=1e9, help="rays for configs 3 and 4")
+    ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--pool-gb", type=float, default=200.0, help="HBM budget for pre-generated bundles")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N>1 path with several ranks sharing one GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % max(1, torch.cuda.device_count())   # (rehearsal: ranks may share a GPU under gloo)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)                         # (rehearsal: ranks may share a GPU under gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -152,8 +373,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     n_gpus = world
 
+    import pyxfocus_amd as pxf
     import pyxfocus_amd.analyses as anal
     import pyxfocus_amd.sources as sources
     import pyxfocus_amd.surfaces as surf
@@ -173,14 +396,14 @@ def main():
     # ---- warm-up -------------------------------------------------------------------------
     for i in range(W):
         b = fresh(-1 - i)
-        chain_step(b, tran, surf)
+        wl.config2_chain(b, tran, surf)
         del b
     torch.cuda.synchronize()
 
     # ---- timed region: EXACTLY K steps -----------------------------------------------------
     bundles = [fresh(i) for i in range(pool)]
     regen = max(0, K - pool)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(K)]
+    marks = [Marks(6) for _ in range(K)]
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -189,7 +412,7 @@ def main():
     for i in range(K):
         if i >= pool:                       # only if K exceeds what HBM can hold pre-generated
             bundles[i % pool] = fresh(i)
-        chain_step(bundles[i % pool], tran, surf, ev[i])
+        wl.config2_chain(bundles[i % pool], tran, surf, marks[i])
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -201,30 +424,16 @@ def main():
         elapsed = float(t.item())
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region -----------
-    per = {}
-    for i in range(K):
-        for j, name in enumerate(CHAIN):
-            per.setdefault((j, name), []).append(ev[i][j].elapsed_time(ev[i][j + 1]))
-    kern = []
-    for (j, name), ms in sorted(per.items()):
-        avg = float(np.mean(ms))
-        kern.append({"launch": j, "kernel": name, "avg_ms": avg, "bytes_per_ray": BYTES[name],
-                     "GBps": BYTES[name] * N / (avg * 1e-3) / 1e9})
+    kern = kernel_table(wl.CONFIG2, [m.ms() for m in marks], N)
     dom = max(kern, key=lambda k: k["avg_ms"])
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            ent = tj.get(dom["kernel"])
-            if ent and int(ent.get("rays", 0)) == N:
-                traffic = ent["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    tr = pmc_entry("pmc_traffic.json", "config2:" + dom["kernel"], N)
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
+                "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                "traffic_source": ("%s @ %s (csrc %s)" % (tr["source"], tr["commit"], csrc_hash())) if tr else
+                "none for the kernel sources of this build (csrc %s): run tools/pmc_collect.py" % csrc_hash(),
                 "algorithmic_bytes_per_launch": dom["bytes_per_ray"] * N, "avg_launch_ms": dom["avg_ms"]}
-    chain_gbps = 576.0 * N * K / (sum(k["avg_ms"] for k in kern) * K * 1e-3) / 1e9
+    chain_gbps = 576.0 * N / (sum(k["avg_ms"] for k in kern) * 1e-3) / 1e9
     # measured device-to-device copy of the same nine columns ("also report against a
     # measured copy kernel") -- what a 9R+9W stream reaches on this GPU with no arithmetic at all
     try:
@@ -254,12 +463,11 @@ def main():
     torch.cuda.empty_cache()
     fused = None
     if not args.no_fused:
-        import pyxfocus_amd as pxf
         fb = [fresh(10_000 + i) for i in range(pool)]
         with pxf.fused():
-            chain_step(fb[0], tran, surf)               # warm-up (first bundle is re-generated below)
+            wl.config2_chain(fb[0], tran, surf)           # warm-up (first bundle is re-generated below)
         fb[0] = fresh(10_000)
-        fev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * K)]
+        fm = [Marks(1) for _ in range(K)]
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -267,10 +475,10 @@ def main():
         for i in range(K):
             if i >= pool:
                 fb[i % pool] = fresh(10_000 + i)
-            fev[2 * i].record()
+            fm[i](0)
             with pxf.fused():
-                chain_step(fb[i % pool], tran, surf)
-            fev[2 * i + 1].record()
+                wl.config2_chain(fb[i % pool], tran, surf)
+            fm[i](1)
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -279,7 +487,7 @@ def main():
             t = torch.tensor([felapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             felapsed = float(t.item())
-        fms = float(np.mean([fev[2 * i].elapsed_time(fev[2 * i + 1]) for i in range(K)]))
+        fms = float(np.mean([m.ms()[0] for m in fm]))
         fused = {"value": N * n_gpus * K / felapsed, "unit": "rays/s", "ms_per_step": felapsed / K * 1e3,
                  "launches_per_step": 1, "algorithmic_bytes_per_ray": 120, "avg_launch_ms": fms,
                  "GBps": 120.0 * N / (fms * 1e-3) / 1e9, "frac_of_hbm_peak": 120.0 * N / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -306,9 +514,12 @@ def main():
             torch.cuda.synchronize(); dist.barrier()
             gather = {"ms": (time.perf_counter() - g0) * 1e3, "rays": int(gx.shape[0]),
                       "GB_received_per_rank": 16.0 * gx.shape[0] * (world - 1) / world / 1e9}
+            gather["GBps_per_rank"] = gather["GB_received_per_rank"] / (gather["ms"] * 1e-3)
             del gx, gy
         except Exception as e:  # the trace result must survive a collective problem
             gather = {"error": repr(e)[:200]}
+    del last
+    torch.cuda.empty_cache()
 
     out = None
     if rank == 0:
@@ -323,22 +534,38 @@ def main():
                                       "launch per PyXFocus call" % N,
                           "rays_per_gpu": N, "launches_per_step": 6, "algorithmic_bytes_per_ray": 576,
                           "parallelism": "ray-sharded x%d, no data-path collective" % n_gpus,
+                          "world_size": dist.get_world_size() if dist else 1,
+                          "backend": (args.backend if dist else None), "devices": ndev,
                           "bundles_pregenerated": pool, "bundles_regenerated_in_timed_region": regen},
                "roofline": roofline,
                "chain_GBps": chain_gbps, "chain_frac_of_hbm_peak": chain_gbps / HBM_PEAK_GBS,
                "kernels": kern, "focal_rms_centroid_mm": rms, "focal_hpd": hpd, "focal_gather": gather,
                "fused": fused}
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if dist and (args.backend != "nccl" or ndev < n_gpus):
+            out["rehearsal"] = ("%d ranks share %d GPU(s), collectives over %s: exercises the N>1 code path, "
+                                "NOT a scaling measurement" % (n_gpus, ndev, args.backend))
+        want = args.configs if args.configs is not None else ("3,4" if n_gpus == 1 else "")
+        cfg = {}
+        for c in [t for t in want.split(",") if t]:
+            try:
+                if c == "3":
+                    cfg["3"] = bench_config3(int(args.config_rays), args.config_steps, dev, pxf, sources, tran, surf, con)
+                elif c == "4":
+                    cfg["4"] = bench_config4(int(args.config_rays), args.config_steps, dev, pxf, sources, tran, surf)
+            except Exception as e:
+                cfg[c] = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
+        if cfg:
+            out["configs"] = cfg
+        if not args.no_cpu_baseline:
             def gpu_chain(cols, use_fused):
                 import contextlib
-                import pyxfocus_amd as pxf
-                order = "opd x y z l m n ux uy uz".split()
-                r = [torch.from_numpy(cols[k]).to(dev) for k in order]
+                r = [torch.from_numpy(cols[k]).to(dev) for k in ORDER]
                 with (pxf.fused() if use_fused else contextlib.nullcontext()):
-                    chain_step(r, tran, surf)
-                return {k: v.cpu().numpy() for k, v in zip(order, r)}
-            try:
-                out["cpu_baseline"] = cpu_baseline(gpu_chain)
+                    wl.config2_chain(r, tran, surf)
+                return {k: v.cpu().numpy() for k, v in zip(ORDER, r)}
+            try:        # (at N>1 the other ranks wait in the barrier below: a shorter sample)
+                out["cpu_baseline"] = cpu_baseline(gpu_chain, 12.0 if n_gpus == 1 else 5.0)
                 # the metric's second half: RMS ray-position error of the GPU path vs the reference
                 out["rms_pos_err_vs_reference_mm"] = out["cpu_baseline"]["parity_vs_gpu"]["rms_pos_err_mm"]
             except Exception as e:

@@ -1,0 +1,106 @@
+"""SURVEY row a13 / f-4 (analyses half): the device reductions against fixtures produced by the
+reference's OWN analyses.py, surfaces.focus* and transformations.steerX/Y (tests/golden/analyses.npz,
+oracle/make_golden.py: imported from /root/reference over the compiled Fortran).  Tolerances: sums
+run in a different (tree) order on the device -> 1e-12 relative on moments-derived scalars; order
+statistics (median, weighted quantile element) are exact selections of the same radii."""
+import numpy as np
+import pytest
+
+from util import ALLCOLS, bits_equal
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+WTAGS = ("none", "smooth", "heavy")
+
+
+def _cases(g):
+    for tag in ("ring", "blob"):
+        cols = [g["%s/in/%s" % (tag, k)] for k in ALLCOLS]
+        for wt in WTAGS:
+            yield tag, wt, cols, (None if wt == "none" else g["%s/%s/w" % (tag, wt)])
+
+
+def _dev(cols):
+    return [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in cols]
+
+
+def _close(got, want, rel=1e-12, abs_=0.):
+    got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
+    return np.all(np.abs(got - want) <= abs_ + rel * np.abs(want))
+
+
+def test_reductions_equal_reference_analyses(golden):
+    import pyxfocus_amd.analyses as anal
+    g = golden["analyses"]
+    for tag, wt, cols, w in _cases(g):
+        rays, pre = _dev(cols), "%s/%s/" % (tag, wt)
+        scale = float(np.abs(np.concatenate([cols[1], cols[2]])).max())
+        # centroid: |err| <= 1e-12 x the coordinate scale (a mean can cancel to ~0)
+        assert _close(anal.centroid(rays, weights=w), g[pre + "centroid"], rel=0., abs_=1e-12 * scale), pre
+        for name in ("rmsCentroid", "rmsX", "rmsY"):
+            assert _close(getattr(anal, name)(rays, weights=w), g[pre + name]), (pre, name)
+        assert _close(anal.rmsPoint(rays, [.1, -.2, .3], weights=w), g[pre + "rmsPoint"]), pre
+        for name in ("analyticImagePlane", "analyticXPlane", "analyticYPlane"):
+            # b/a with b, a differences of O(1) averages: conditioning ~ <x l/n> / b
+            assert _close(getattr(anal, name)(rays, weights=w), g[pre + name], rel=1e-9), (pre, name)
+        got = anal.rho(rays, weights=w, cent=True).cpu().numpy()
+        assert np.abs(got - g[pre + "rho_cent"]).max() <= 1e-12 * scale, pre
+        # order statistics: the same elements are selected; their VALUES carry the centroid's 1e-12
+        assert _close(anal.hpd(rays, weights=w), g[pre + "hpd"], rel=0., abs_=4e-12 * scale), (pre, "hpd")
+        assert _close(anal.hpdY(rays, weights=w), g[pre + "hpdY"], rel=0., abs_=4e-12 * scale), (pre, "hpdY")
+        r, cdf = anal.rhocdf(rays, weights=w)
+        assert np.abs(r.cpu().numpy() - g[pre + "rhocdf_r"]).max() <= 1e-12 * scale
+        assert np.abs(cdf.cpu().numpy() - g[pre + "rhocdf_cdf"]).max() <= 1e-12
+    for tag in ("ring", "blob"):
+        cols = [g["%s/in/%s" % (tag, k)] for k in ALLCOLS]
+        rays, sel = _dev(cols), g[tag + "/sel"]
+        assert bits_equal(anal.rho(rays).cpu().numpy(), g[tag + "/rho_origin"]).all()       # sqrt(x^2+y^2): no sums
+        assert bits_equal(anal.measureOPD(rays, [.1, -.2, .3]).cpu().numpy(), g[tag + "/measureOPD"]).all()
+        pt = [float(c[7]) for c in cols]
+        assert bits_equal(anal.measureOPD(rays, pt).cpu().numpy(), g[tag + "/measureOPD_ray"]).all()
+        assert _close(anal.rmsPoint(rays, pt), g[tag + "/rmsPoint_ray"])
+        # acos from ocml instead of glibc: 1e-14 away from |dot| = 1, where acos is ill-conditioned
+        for name, kw, key in (("indAngle", {}, "/indAngle"), ("grazeAngle", {}, "/grazeAngle"),
+                              ("indAngle", {"ind": sel}, "/indAngle_sel"), ("grazeAngle", {"ind": sel}, "/grazeAngle_sel"),
+                              ("indAngle", {"normal": [0., .6, .8]}, "/indAngle_normal"),
+                              ("indAngle", {"ind": sel, "normal": [0., .6, .8]}, "/indAngle_normal_sel")):
+            got, want = getattr(anal, name)(rays, **kw).cpu().numpy(), g[tag + key]
+            assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want)), (tag, key)
+            f = ~np.isnan(want)
+            assert np.abs(got[f] - want[f]).max() <= 1e-13, (tag, key, np.abs(got[f] - want[f]).max())
+
+
+def test_focus_equals_reference_surfaces(golden):
+    """surfaces.focusI/X/Y (surfaces.py:502-519): shift, coords bookkeeping and the refocused rays."""
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    g = golden["analyses"]
+    for tag, wt, cols, w in _cases(g):
+        pre = "%s/%s/" % (tag, wt)
+        for fname in ("focusI", "focusX", "focusY"):
+            rays, coords = _dev(cols), tran.newCoords()
+            dz = getattr(surf, fname)(rays, weights=w, coords=coords)
+            want = float(g[pre + fname + "/dz"])
+            assert abs(dz - want) <= 1e-9 * abs(want) + 1e-12, (pre, fname, dz, want)
+            assert np.abs(np.array(coords) - g[pre + fname + "/coords"]).max() <= 1e-9 * abs(want) + 1e-12
+            # rays moved by dz along their own direction: dx = dz l/n; slopes here are O(1) at most
+            for j, k in ((1, "x"), (2, "y")):
+                err = np.abs(rays[j].cpu().numpy() - g[pre + fname + "/out/" + k])
+                slope = np.abs(cols[4 if k == "x" else 5] / cols[6])
+                assert (err <= 2e-9 * abs(want) * (1. + slope) + 1e-11).all(), (pre, fname, k, err.max())
+            assert not rays[3].any() and bool((rays[9] == 1).all())
+
+
+def test_steer_equals_reference_transformations(golden):
+    import pyxfocus_amd.transformations as tran
+    g = golden["analyses"]
+    for tag in ("ring", "blob"):
+        cols = [g["%s/in/%s" % (tag, k)] for k in ALLCOLS]
+        for fname in ("steerX", "steerY"):
+            rays, coords = _dev(cols), tran.newCoords()
+            getattr(tran, fname)(rays, coords=coords)
+            assert np.abs(np.array(coords) - g["%s/%s/coords" % (tag, fname)]).max() <= 1e-12
+            for k, r in zip(ALLCOLS, rays):
+                want = g["%s/%s/out/%s" % (tag, fname, k)]
+                assert np.abs(r.cpu().numpy() - want).max() <= 1e-11 * (1. + np.abs(want).max()), (tag, fname, k)

@@ -154,7 +154,13 @@ def test_bench_cli_and_chain_definition():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert sum(mod.BYTES[k] for k in mod.CHAIN) == 576
+    from tools import workloads as wl
+    assert sum(b for _, b in wl.CONFIG2) == wl.BYTES["config2"] == 576
+    assert sum(b for _, b in wl.CONFIG3) == wl.BYTES["config3"] == 1192
+    assert sum(b for _, b in wl.CONFIG4) == wl.BYTES["config4"] == 264
+    assert len(mod.csrc_hash()) == 16
+    # --gpus N without a launcher must start the ranks itself, before any GPU call
+    assert "launch_ranks" in src and src.index("launch_ranks(args") < src.index("torch.cuda.set_device")
 
 
 def test_program_planner_liveness():
