@@ -99,7 +99,21 @@ def host_cores():
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except Exception:
         pass
-    return int(os.environ.get("OMP_NUM_THREADS", 0)) or cores
+    # torch.distributed.run exports OMP_NUM_THREADS=1 into every rank: not the user's choice, ignore it there
+    user = 0 if "TORCHELASTIC_RUN_ID" in os.environ else int(os.environ.get("OMP_NUM_THREADS", 0))
+    return int(os.environ.get("PXF_CPU_THREADS", 0)) or user or cores
+
+
+def set_omp_threads(n):
+    """The environment variable only counts before an OpenMP runtime initialises; torch may have
+    initialised one already, so also tell every loaded runtime directly."""
+    import ctypes
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    for lib in ("/opt/rocm/lib/llvm/lib/libomp.so", "libomp.so", "libgomp.so.1"):
+        try:
+            ctypes.CDLL(lib, mode=ctypes.RTLD_GLOBAL).omp_set_num_threads(int(n))
+        except (OSError, AttributeError):
+            pass
 
 
 def checker(omp):
@@ -120,8 +134,9 @@ def cpu_baseline(gpu_chain, target_seconds=12.0):
     compared: the checker's only other job in this file."""
     from oracle import cases
     cores = host_cores()
-    os.environ["OMP_NUM_THREADS"] = str(cores)          # before the OpenMP runtime initialises
+    set_omp_threads(cores)
     be, kind = checker(omp=True)
+    set_omp_threads(cores)
     n = 10_000_000
     rng = np.random.default_rng(0)
     rin, rout = cases.primrad(Z0), cases.primrad(Z0 + LMIR)

@@ -51,7 +51,10 @@ constexpr ZernH make_zern_h()
     return t;
 }
 static __device__ __constant__ const ZernH kZernH = make_zern_h();
-constexpr bool zern_h_in_lds(int nmax) { return nmax >= 8; }
+#ifndef PXF_ZERN_HLDS_FROM
+#define PXF_ZERN_HLDS_FROM 8  // (dev builds of tools/zern_repro.sh override this and PXF_ZERN_LOOP_FROM)
+#endif
+constexpr bool zern_h_in_lds(int nmax) { return nmax >= PXF_ZERN_HLDS_FROM; }
 
 template <int NMAX, bool HLDS>
 __device__ __forceinline__ double (*zern_h_lds())[3]
@@ -78,7 +81,10 @@ __device__ __forceinline__ void zern_h_stage()  // call before the block-wide ba
 // angle-addition recurrence (three consecutive multiples are kept), and within a chain of fixed n
 // they DEscend by two with  cos((m-2)t) = 2 cos(2t) cos(m t) - cos((m+2)t)  (same for sin); the
 // powers rho'^n .. rho'^(n-3) are a sliding window.  Same radial q-recursion, same accumulation order.
-constexpr int kZernLoopFrom = 9;
+#ifndef PXF_ZERN_LOOP_FROM
+#define PXF_ZERN_LOOP_FROM 9
+#endif
+constexpr int kZernLoopFrom = PXF_ZERN_LOOP_FROM;
 
 __device__ __forceinline__ void zern_eval_loop(const double2 *__restrict__ tab, const double (*__restrict__ hq)[3],
                                                int nmax, double x, double y, double rad, double inv_rad, double &S,
@@ -241,6 +247,9 @@ __device__ __forceinline__ void zern_eval(const double2 *__restrict__ tab, doubl
 // conic"; the reference's zernsurf is a pure Zernike sag): the sag of a conic of radius
 // R and constant K is added under the Zernike sum,  F = z - c rho^2/(1+sqrt(1-(K+1) c^2 rho^2)) - S.
 // Parity unpinned; checked against the conic kernel (coeff = 0) and an independent NumPy Newton.
+#ifdef PXF_ZERN_MIN_WAVES_ALL   // dev builds (tools/zern_repro.sh): one occupancy target for every order
+#define PXF_ZERN_MIN_WAVES(NMAX) PXF_ZERN_MIN_WAVES_ALL
+#endif
 #ifndef PXF_ZERN_MIN_WAVES
 // >= 2 waves per SIMD keeps a kernel within 256 registers per lane.  Beyond that the compiler parks
 // values in AGPRs, and the NMAX = 15 program kernel built that way returned 1/rad in the x column

@@ -272,6 +272,26 @@ struct LLOp : LLData {
 // identities; results move by rounding only, far inside the 2e-8 mm these surfaces are held to (the
 // reference's own 1.e-8 stopping step).  Branch tests use the same monotone images
 // (beta <= betas  <=>  sin beta <= sin betas on [0, pi/2];  <=>  cos beta >= cos betas on [0, pi]).
+// RN(z / sqrt(r*r + z*z)): the quotient formed in double-double arithmetic (error ~1e-31) and rounded
+// to double once.  Explicit fma() calls fuse regardless of -ffp-contract=off.
+__device__ __forceinline__ double cos_of_ratio_rn(double r, double z)
+{
+    const double h1 = r * r, l1 = fma(r, r, -h1);
+    const double h2 = z * z, l2 = fma(z, z, -h2);
+    double sh = h1 + h2;
+    const double bb = sh - h1;
+    double sl = ((h1 - (sh - bb)) + (h2 - bb)) + (l1 + l2);     // two_sum error + the product tails
+    const double t = sh + sl;
+    sl = sl - (t - sh);
+    sh = t;
+    const double ph = sqrt(sh);
+    const double pe = fma(-ph, ph, sh) + sl;                    // s - ph^2
+    const double pl = pe / (2 * ph);
+    const double qh = z / ph;
+    const double ql = (fma(-qh, ph, z) - qh * pl) / ph;
+    return qh + ql;
+}
+
 template <bool SECONDARY, bool BACK = false>
 struct WSOp {
     PXF_OP_DEFAULTS
@@ -343,7 +363,13 @@ struct WSOp {
                 } else {
                     const double r3 = r2 + z * z;
                     const double qq = sqrt(r3);
-                    const double cb = z / qq, sb = rr / qq;  // cos, sin of beta = atan2(rr, z)
+                    const double sb = rr / qq;                 // sin of beta = atan2(rr, z)
+                    // cos(beta) must carry the reference's OWN rounding: its `a` holds (1 - cos beta) with
+                    // cos beta ~ 1 - 3e-4, so one ulp of cos beta moves the converged z by ~2.6e-9 mm (1e-16 /
+                    // 3e-4 x 8400 mm).  glibc's cos(atan2(rr, z)) is the correctly rounded cosine of the
+                    // angle of the DOUBLES (rr, z) in all but ~1e-3 of the cases, so that is what is
+                    // formed here: z / sqrt(rr^2 + z^2) in double-double, rounded once.
+                    const double cb = cos_of_ratio_rn(rr, z);
                     const bool flag = cb >= cbs;              // beta <= betas
                     if (flag) {
                         F = -z + cbs * ff;  // cos(betas) / a, a = 1/ff

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""CHILD-PROCESS helper of tests/test_gpu_parity.py::test_nontemporal_instantiations_in_child_process.
+
+Must be started with PXF_NT_MIN_RAYS=0 in the environment: the library then launches the NT=true
+instantiation of every ray kernel (non-temporal loads / stores -- what every bundle above 3.3M rays
+runs) even for the small bundles the oracle can check.  Re-runs, on those code objects: every case of
+oracle/cases.py plain and masked, the fused two-bounce program, and the Zernike sweep over all 15
+radial orders plain and masked.  Prints "nt sweep ok" and exits 0, or raises."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+from oracle import api, cases  # noqa: E402
+from util import ALLCOLS, assert_cols, bits_equal, call_gpu, to_dev, to_host, zernike_order_check  # noqa: E402
+
+
+def main():
+    assert os.environ.get("PXF_NT_MIN_RAYS") == "0", "start me with PXF_NT_MIN_RAYS=0"
+    port = api.load_port()
+    rng = np.random.default_rng(17)
+    ncase = 0
+    for name, fn, cols, args in cases.cases(num=3001, seed=777):
+        want = {k: v.copy() for k, v in cols.items()}
+        cases.call(port, fn, want, args)
+        t = to_dev(cols)
+        call_gpu(fn, t, args)
+        assert_cols(fn, to_host(t), want, ALLCOLS, context="nt:" + name)
+        n = len(cols["x"])
+        msk = rng.random(n) < .37
+        want = {k: v.copy() for k, v in cols.items()}
+        sub = {k: np.ascontiguousarray(v[msk]) for k, v in cols.items()}
+        a2 = tuple(a[msk] if (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.shape == (n,)) else a
+                   for a in args)
+        cases.call(port, fn, sub, a2)
+        for k in ALLCOLS:
+            want[k][msk] = sub[k]
+        t = to_dev(cols)
+        call_gpu(fn, t, args, mask=torch.from_numpy(msk).cuda())
+        got = to_host(t)
+        assert_cols(fn, got, want, ALLCOLS, context="nt masked:" + name)
+        for k in ALLCOLS:
+            assert bits_equal(got[k][~msk], cols[k][~msk]).all(), (name, k)
+        ncase += 1
+    # the fused two-bounce program, NT instantiation
+    import pyxfocus_amd as pxf
+    from pyxfocus_amd import native
+    c = cases.annulus_rays(rng, 5001, cases.primrad(cases.Z0), cases.primrad(cases.Z0 + cases.LMIR), 0.)
+    want = {k: v.copy() for k, v in c.items()}
+    cases.chain_config2(port, want)
+    t = to_dev(c)
+    with pxf.fused() as rec:
+        cases.chain_config2(native, t)
+    assert rec.launches == 1
+    for k, v in to_host(t).items():
+        assert bits_equal(v, want[k]).all(), k
+    for nmax in range(1, 16):
+        zernike_order_check(port, nmax)
+        zernike_order_check(port, nmax, masked=True)
+    torch.cuda.synchronize()
+    print("nt sweep ok: %d cases x (plain, masked), fused chain, 15 Zernike orders x (plain, masked)" % ncase)
+
+
+if __name__ == "__main__":
+    main()

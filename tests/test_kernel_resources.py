@@ -1,10 +1,15 @@
 """Audit of the built code objects (CPU test: reads the AMDGPU metadata notes of libpxf_hip.so).
 
-Round 1 found Zernike kernel instantiations that returned WRONG results whenever the register
-allocator had to spill heavily (AGPRs, or scalar registers spilled while the vector file was full):
-DESIGN.md 3.1.  This test keeps every kernel of the library out of that regime: no kernel may use
-AGPRs, and vector-register spills are allowed only for the short list below (a handful of registers
-each, all covered by parity tests over their whole parameter range)."""
+Round 1 found Zernike kernel instantiations that returned WRONG results; round 2 found the cause
+(DESIGN.md 3.1): when a kernel needs more than 256 registers the compiler (ROCm 7.2 clang) spills
+VGPRs into AGPRs, and its "Reload Reuse" path can drop the copy of one 32-bit HALF of a 64-bit value --
+the consumer then reads an AGPR that no instruction of the kernel ever writes (order 13: the low dword
+of one folded Zernike coefficient -> a 4e-7 relative error in one term -> 3e-10 mm in z).  This test
+keeps every kernel of the library out of that regime: no kernel may use AGPRs (so the faulty path is
+never taken), no kernel may read a register file entry it never writes (the signature itself, checked
+on the disassembly), and vector-register spills to scratch -- a different, unaffected mechanism -- stay
+limited to the short list below (a handful of registers each, covered by parity tests over their
+whole parameter range)."""
 import glob
 import os
 import re
@@ -65,3 +70,47 @@ def test_no_kernel_in_the_heavy_spill_regime():
         if f.get("vgpr_count", 0) > 256:
             bad.append(("more than 256 registers", name[:100], f))
     assert not bad, bad[:10]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="needs the ROCm LLVM tools")
+def test_no_kernel_reads_an_agpr_it_never_writes():
+    """The miscompile signature itself (tools/isa_spills.py: undefined_agprs) on the disassembly of every
+    code object of the built library.  With agpr_count == 0 everywhere this is vacuous today; it is the
+    tripwire for the day a kernel is allowed back above 256 registers."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_spills
+    tmp = tempfile.mkdtemp()
+    try:
+        lib = os.path.join(tmp, "lib.so")
+        shutil.copy(LIB, lib)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], check=True, capture_output=True)
+        nk, bad = 0, []
+        for co in glob.glob(lib + ".*hipv4*"):
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True,
+                                 capture_output=True, text=True).stdout
+            for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+                m = re.match(r"[0-9a-f]+ <(\S+)>:", blk)
+                if not m:
+                    continue
+                nk += 1
+                body = [re.sub(r"//.*", "", ln).strip() for ln in blk.split("\n")[1:]]
+                und = isa_spills.undefined_agprs(body)
+                if und:
+                    bad.append((m.group(1)[:80], und[:4]))
+        assert nk > 300 and not bad, bad[:5]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_agpr_scanner_recognises_the_recorded_miscompile():
+    """The scanner on a hand-made excerpt with the shape of the order-13 kernel's code (two 32-bit
+    halves parked in AGPRs, one half copied back, BOTH read): it must name the unwritten register."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_spills
+    body = ["v_accvgpr_write_b32 a190, v43", "v_accvgpr_write_b32 a191, v42", "ds_read_b128 a[66:69], v4 offset:272",
+            "v_accvgpr_mov_b32 a53, a190", "v_accvgpr_read_b32 v26, a52", "v_accvgpr_read_b32 v27, a53",
+            "scratch_store_dwordx4 off, a[66:69], off offset:16"]
+    assert isa_spills.undefined_agprs(body) == [52]
+    assert isa_spills.undefined_agprs(body + ["v_accvgpr_mov_b32 a52, a191"]) == []
