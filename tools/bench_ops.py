@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=float, default=1e8)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="", help="comma list of op-name prefixes (default: every op)")
     a = ap.parse_args()
     N = int(a.rays)
     rin, rout = float(con.primrad(Z0, R0, Z0)), float(con.primrad(Z0 + L, R0, Z0))
@@ -43,6 +44,12 @@ def main():
     def secondary_in():                    # after primary + reflect
         r = wolter_in()
         surf.wolterprimary(r, R0, Z0)
+        tran.reflect(r)
+        return r
+
+    def ws_secondary_in():                 # after a W-S primary + reflect
+        r = wolter_in()
+        surf.wsPrimary(r, R0, Z0, PSI)
         tran.reflect(r)
         return r
 
@@ -110,6 +117,8 @@ def main():
          lambda r: surf.secondaryLL(r, R0, Z0, PSI, Z0, Z0 - L, 2 * np.pi, llc, lla, llz), 96),
         ("wsPrimary", wolter_in, lambda r: surf.wsPrimary(r, R0, Z0, PSI), 96),
         ("wsPrimaryB", wolter_in, lambda r: surf.wsPrimaryB(r, R0, Z0, PSI, .4), 96),
+        ("wsSecondary", ws_secondary_in, lambda r: surf.wsSecondary(r, R0, Z0, PSI), 96),
+        ("wsSecondaryB", ws_secondary_in, lambda r: surf.wsSecondaryB(r, R0, Z0, PSI, .4), 96),
         ("spoCone", wolter_in, lambda r: surf.spoPrimary(r, R0, Z0), 96),
         ("conic", lambda: beam(z=50.), lambda r: surf.conic(r, 2000., -1.), 96),
         ("conicopd", lambda: beam(z=50.), lambda r: surf.conic(r, 2000., -1., nr=1.), 112),
@@ -148,7 +157,10 @@ def main():
         return c
 
     out = {"rays": N, "reps": a.reps, "hbm_peak_GBps": HBM, "device": torch.cuda.get_device_name(0), "ops": []}
+    only = [t for t in a.only.split(",") if t]
     for name, build, call, bpr in ops:
+        if only and not any(name == t or name.startswith(t + " ") for t in only):
+            continue
         try:
             base = build()
             torch.cuda.synchronize()
@@ -178,7 +190,7 @@ def main():
             out["ops"].append({"op": name, "error": repr(e)[:200]})
         print(json.dumps(out["ops"][-1]), file=sys.stderr, flush=True)
     # reconstruct: one workgroup, latency-bound -- report time per sweep for two grid sizes
-    for dim in (64, 128, 200):
+    for dim in (() if only else (64, 128, 200)):
         try:
             g = torch.Generator(device="cpu").manual_seed(dim)
             yy, xx = torch.meshgrid(torch.linspace(-1, 1, dim, dtype=torch.float64),
