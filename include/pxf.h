@@ -515,6 +515,22 @@ int pxf_source_segments(int32_t kind, double *const *cols, int64_t num, const do
                         int32_t nseg, int64_t rays_per_seg, uint64_t seed, uint64_t first_index,
                         pxf_stream_t stream);
 
+/* ---- OPT-IN tolerance mode of the fused program ------------------------------------------------------
+ * pxf_program_run / pxf_program_run_segments are bit-identical to the reference's loops
+ * (surfacesf.f95 / woltsurf.f95 / transformationsf.f95) and, for Newton-heavy programs, bound by IEEE
+ * fp64 divides instead of HBM.  The _fast entries run the same program to a TOLERANCE instead: the
+ * Wolter-I Newton loops iterate the exact quadratic F(s) along the ray (same steps, same stopping
+ * rule, same stale-gradient normal as woltsurf.f95:28-47,134-154), divides and square roots are
+ * reciprocal / rsqrt refinements, FMA contraction is on.  Agreement with the reference: inside the
+ * reference's own rounding jitter (its focal positions move by ~5e-11 mm RMS under a 1-ulp change of
+ * an input) -- < 1e-10 mm RMS on the BASELINE configs, asserted in tests/.
+ * Supported operations: FLAT, TRANSFORM, ITRANSFORM, REFLECT, WOLTERPRIMARY, WOLTERSECONDARY,
+ * RADGRAT, SPOCONE, unmasked; anything else returns PXF_ERANGE and nothing is launched (run the exact
+ * entry instead).  Never selected implicitly. */
+int pxf_program_run_fast(const pxf_op_t *ops, int32_t nops, double *const *cols, int64_t num, pxf_stream_t stream);
+int pxf_program_run_segments_fast(const pxf_op_t *ops, int32_t nops, const double *seg_params_dev, int32_t nseg,
+                                  int64_t rays_per_seg, double *const *cols, int64_t num, pxf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
