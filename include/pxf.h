@@ -213,6 +213,13 @@ int pxf_tracezernrot(double *x, double *y, double *z, const double *l, const dou
                      const int32_t *rorder1, const int32_t *aorder1, int32_t arrsize1, const double *coeff2,
                      const int32_t *rorder2, const int32_t *aorder2, int32_t arrsize2, double rad, double rot,
                      const uint8_t *mask, pxf_stream_t stream);
+/* Host utility (no GPU): the bivariate polynomial the Zernike kernels of radial order <= 10 evaluate.
+ * sum_i coeff_i Z_i(rho, theta) -- the reference's normalised Zernikes, zernset specialFunctions.f95:142-232
+ * -- expanded into monomials of u = x/rad, v = y/rad:  out[j*(degree+1) - j*(j-1)/2 + i] multiplies
+ * u^(degree-j-i) v^j  (Horner order; (degree+1)(degree+2)/2 doubles; degree >= the largest rorder, <= 15). */
+int pxf_zernike_monomials(const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
+                          int32_t degree, double *out);
+
 /* zernphase(opd,x,...,uz,num,coeff,rorder,aorder,arrsize,rad,wave)   zernsurf.f95:206-250
  * Zernike phase plate in the z=0 plane; only opd,x,y,l,m,n are touched. */
 int pxf_zernphase(double *opd, const double *x, const double *y, double *l, double *m, double *n, int64_t num,

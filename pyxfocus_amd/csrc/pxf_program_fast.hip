@@ -31,38 +31,10 @@
 // exact kernel.
 #include <stdlib.h>
 
+#include "pxf_fastmath.h"
 #include "pxf_program.h"
 
 namespace pxf {
-
-// ---- fast fp64 primitives -----------------------------------------------------------------------
-__device__ __forceinline__ double f_rcp(double a)
-{
-    double r = __builtin_amdgcn_rcp(a);
-    double e = fma(-a, r, 1.);
-    r = fma(e, r, r);
-    e = fma(-a, r, 1.);
-    return fma(e, r, r);
-}
-__device__ __forceinline__ double f_div(double x, double y)
-{
-    const double r = f_rcp(y);
-    const double q = x * r;
-    return fma(fma(-y, q, x), r, q);
-}
-__device__ __forceinline__ double f_rsq(double a)  // 1/sqrt(a), a > 0 finite
-{
-    double y = __builtin_amdgcn_rsq(a);
-    double e = fma(-a * y, y, 1.);
-    y = fma(.5 * y, e, y);
-    e = fma(-a * y, y, 1.);
-    return fma(.5 * y, e, y);
-}
-__device__ __forceinline__ double f_sqrt(double a)  // sqrt(a); 0 -> 0, negative -> NaN
-{
-    const double s = a * f_rsq(a);
-    return a == 0. ? 0. : s;
-}
 
 // ---- Newton on a quadratic along the ray -----------------------------------------------------------
 // s_0 = 0;  s_{k+1} = s_k - F(s_k)/F'(s_k)  while |step| > tol (the reference's loop on the 3-D point,
@@ -163,7 +135,7 @@ __device__ __forceinline__ void fast_flat(Ray (&r)[V])
 #pragma unroll
     for (int k = 0; k < V; k++) {
         double *c = r[k].c;
-        const double dd = (double)(float)(-f_div(c[Z], c[N]));  // fp32 `delta` of surfacesf.f95:4-15
+        const double dd = (double)(float)(-f_div_ieee_edges(c[Z], c[N]));  // fp32 `delta` of surfacesf.f95:4-15
         c[X] = fma(dd, c[L], c[X]);
         c[Y] = fma(dd, c[M], c[Y]);
         c[Z] = 0.;
@@ -260,9 +232,9 @@ __device__ __forceinline__ void fast_spocone(const double *__restrict__ P, Ray (
         const double C = R0 * R0 + 2 * sl * R0 * z + z * z * sl2 - x * x - y * y;
         const double det = Bq * Bq - 4 * A * C;
         if (det >= 0) {
-            const double sq = f_sqrt(det), i2a = f_rcp(2 * A);
-            double t1 = (-Bq + sq) * i2a;
-            const double t2 = (-Bq - sq) * i2a;
+            const double sq = f_sqrt(det);
+            double t1 = f_div_ieee_edges(-Bq + sq, 2 * A);
+            const double t2 = f_div_ieee_edges(-Bq - sq, 2 * A);
             if (fabs(t2) < fabs(t1)) t1 = t2;
             const double xn = fma(t1, l, x), yn = fma(t1, m, y);
             c[X] = xn;

@@ -17,9 +17,6 @@ namespace pxf {
 #ifndef PXF_ZPROG_WAVES
 #define PXF_ZPROG_WAVES 3
 #endif
-#ifndef PXF_ZPROG_HLDS
-#define PXF_ZPROG_HLDS false
-#endif
 constexpr int kMaxOpsZ = PXF_PROGRAM_MAX_OPS_ZERN;
 constexpr int kZernFusedMaxN = PXF_PROGRAM_ZERN_MAX_ORDER;
 
@@ -29,7 +26,7 @@ struct ProgramZ {  // a Program cut to the operation count a Zernike program may
     ProgOp op[kMaxOpsZ];
 };
 
-static_assert(sizeof(ProgramZ) + sizeof(ZernOp<kZernFusedMaxN, false, PXF_ZPROG_HLDS>) + sizeof(Cols) + 64 <= 4096,
+static_assert(sizeof(ProgramZ) + sizeof(ZernOp<kZernFusedMaxN, false>) + sizeof(Cols) + 64 <= 4096,
               "program + Zernike table must fit the kernel-argument segment");
 
 // (three waves per SIMD like the stand-alone order-7 kernel: 168 registers, eight of them spilled.  With
@@ -64,7 +61,7 @@ __device__ __forceinline__ void exec_op_lite(int code, int flags, const double *
 
 template <int NMAX, bool NT, bool ANYMASK>
 __global__ __launch_bounds__(kBlock, PXF_ZPROG_WAVES) void program_zern_kernel(Cols c, int64_t num, ProgramZ pg,
-                                                                                      ZernOp<NMAX, false, PXF_ZPROG_HLDS> zop, int iz)
+                                                                                      ZernOp<NMAX, false> zop, int iz)
 {
     constexpr int V = 1;
     zop.prologue();  // Zernike table -> LDS (contains the barrier: before any thread may exit)
@@ -114,8 +111,8 @@ template <int NMAX>
 static int launch_zern_nmax(const ProgramZ &pz, int iz, const ZernTab &tab, const Cols &c, int64_t num,
                             pxf_stream_t stream)
 {
-    ZernOp<NMAX, false, PXF_ZPROG_HLDS> zop{};
-    for (int i = 0; i < zern_npairs(NMAX); i++) zop.tab_arg[i] = tab.a[i];
+    ZernOp<NMAX, false> zop{};
+    zern_fill_table<NMAX>(zop.tab_arg, tab);
     zop.rad = pz.op[iz].p[0];
     zop.nr = pz.op[iz].p[1];
     zop.has_opd = pz.op[iz].code == PXF_OP_TRACEZERNOPD;

@@ -1,22 +1,15 @@
 // pxf_zernike.hip -- Newton trace to a Zernike sag surface: tracezern / tracezernOPD
-// (zernsurf.f95:8-101 / 108-203) with zernset (specialFunctions.f95:142-232) inlined.
+// (zernsurf.f95:8-101 / 108-203) with zernset (specialFunctions.f95:142-232) replaced by a polynomial.
 //
-// What the reference does per Newton step and per ray: two heap allocations, pow(rho,n),
-// atan2, and 3 x arrsize sin/cos(m*theta) calls (~3.1 us/ray for 36 terms on one CPU core).
-// What this kernel does instead (MI355X-first, fp64 VALU-bound, no transcendentals at all):
-//   * theta never materialises: cos(theta)=x/rho, sin(theta)=y/rho, and cos/sin(m*theta) come
-//     from the angle-addition recurrence (m <= 15);
-//   * rho'^n is a running product; the radial polynomials R_n^m, dR_n^m/drho' follow the
-//     REFERENCE's own downward q-recursion (specialFunctions.f95:187-199), whose coefficients
-//     h1,h2,h3 depend only on (n,m) and are compile-time constants of the fully unrolled body;
-//   * the user's (coeff, rorder, aorder) list is folded ON THE HOST into one (Ac, As) pair per
-//     (n,|m|) -- cos-type and sin-type amplitude including the sqrt(2(n+1)) normalisation (and
-//     the reference's single-precision sqrt(0.5) for m=0, specialFunctions.f95:225) -- and that
-//     table is staged in LDS once per workgroup; every lane reads the same address (broadcast);
-//   * one ray per thread (VALU-bound: wide loads buy nothing, fewer VGPRs do).
-// Parity is to a stated tolerance, not bitwise: summation order over terms, recurrences instead of
-// libm, and FMA contraction (this TU only) all differ from the reference at the 1e-16 level, and
-// the Newton iteration contracts those differences quadratically.  See DESIGN.md.
+// What the reference does per Newton step and per ray: two heap allocations, pow(rho,n), atan2, and
+// 3 x arrsize sin/cos(m*theta) calls (~3.1 us/ray for 36 terms on one CPU core).
+// What these kernels do instead (pxf_ops_zernike.h): the whole Zernike sum is one bivariate polynomial in
+// (x/rad, y/rad); the host expands the caller's (coeff, rorder, aorder) into its monomial coefficients,
+// the table is staged in LDS once per workgroup, and every evaluation of S, dS/dx, dS/dy is a nested
+// Horner scheme -- 80 FMAs for 36 terms, no transcendental, no divide.  Two rays per thread with 16-byte
+// accesses like every other streaming kernel; HBM-bound up to radial order 8.
+// Parity is to a stated tolerance, not bitwise (different arithmetic altogether; the Newton iteration
+// contracts the differences quadratically): 2e-11 mm asserted, ~1e-14 observed.  See DESIGN.md.
 #include <math.h>
 
 #include "pxf_kernel.h"
@@ -33,18 +26,17 @@ struct ZernPhaseOp {
     static constexpr int MIN_WAVES = 2;  // stay within 256 registers: see PXF_ZERN_MIN_WAVES
     static constexpr unsigned RD = B(OPD) | B(X) | B(Y) | DIR;
     static constexpr unsigned WR = B(OPD) | DIR;
-    double2 tab_arg[zern_npairs(NMAX)];
+    double tab_arg[zern_nmono(NMAX)];
     double rad, wave;
-    __device__ __forceinline__ double2 *lds() const
+    __device__ __forceinline__ double *lds() const
     {
-        __shared__ double2 s_tab[zern_npairs(NMAX)];
+        __shared__ double s_tab[zern_nmono(NMAX)];
         return s_tab;
     }
     __device__ __forceinline__ void prologue() const
     {
-        double2 *s = lds();
-        for (int i = threadIdx.x; i < zern_npairs(NMAX); i += kBlock) s[i] = tab_arg[i];
-        zern_h_stage<NMAX>();
+        double *s = lds();
+        for (int i = threadIdx.x; i < zern_nmono(NMAX); i += kBlock) s[i] = tab_arg[i];
         __syncthreads();
     }
     template <int V>
@@ -52,7 +44,7 @@ struct ZernPhaseOp {
     {
         double *c = r[0].c;
         double S, Sx, Sy;
-        zern_eval<NMAX>(lds(), c[X], c[Y], rad, 1. / rad, S, Sx, Sy);
+        zern_eval<NMAX>(lds(), c[X], c[Y], 1. / rad, S, Sx, Sy);
         c[L] = c[L] + Sx * wave;
         c[M] = c[M] + Sy * wave;
         c[N] = copysign(sqrt(1. - c[L] * c[L] - c[M] * c[M]), c[N]);
@@ -68,7 +60,7 @@ static int launch_nmax(const Cols &c, int64_t num, const uint8_t *mask, pxf_stre
     ZernOpSel<NMAX, WOPD, CONIC> op;
     op.cc = cc;
     op.K1 = K1;
-    for (int i = 0; i < zern_npairs(NMAX); i++) op.tab_arg[i] = tab.a[i];
+    zern_fill_table<NMAX>(op.tab_arg, tab);
     op.rad = rad;
     op.nr = nr;
     op.has_opd = WOPD;
@@ -150,7 +142,7 @@ static int dispatch_phase(int nmax, const Cols &c, int64_t num, const uint8_t *m
     } else {
         if (nmax >= NMAX || NMAX == 1) {
             ZernPhaseOp<NMAX> op;
-            for (int i = 0; i < zern_npairs(NMAX); i++) op.tab_arg[i] = tab.a[i];
+            zern_fill_table<NMAX>(op.tab_arg, tab);
             op.rad = rad;
             op.wave = wave;
             return launch_rays(c, num, mask, stream, op);
@@ -223,6 +215,18 @@ int pxf_tracezernrot(double *x, double *y, double *z, const double *l, const dou
     rc = fold_table(coeff2, rorder2, aorder2, arrsize2, tab, nmax, rot, true);
     if (rc != PXF_OK) return rc;
     return run_table<false>(tab, nmax, nullptr, x, y, z, l, m, n, ux, uy, uz, num, rad, 0., mask, stream);
+}
+
+int pxf_zernike_monomials(const double *coeff, const int32_t *rorder, const int32_t *aorder, int32_t arrsize,
+                          int32_t degree, double *out)
+{
+    ZernTab tab;
+    int nmax = 0;
+    int rc = fold_table(coeff, rorder, aorder, arrsize, tab, nmax);
+    if (rc != PXF_OK) return rc;
+    if (!out || degree < nmax || degree > kZernMaxN) return PXF_EINVAL;
+    zern_monomials(tab, degree, out);
+    return PXF_OK;
 }
 
 int pxf_zernphase(double *opd, const double *x, const double *y, double *l, double *m, double *n, int64_t num,

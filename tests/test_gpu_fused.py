@@ -442,7 +442,9 @@ def _rms_focal(got, want):
     flip = d > 1e-7
     assert (d[flip] < 2e-3).all()                            # bounded by the fp32 quantum of an ~8 m leg
     rest = d[~flip]
-    return float(np.sqrt((rest ** 2).mean())), float(rest.max()), float(f.mean()), int(flip.sum()), len(d)
+    ok = f.copy()
+    ok[f] = ~flip
+    return float(np.sqrt((rest ** 2).mean())), float(rest.max()), float(f.mean()), int(flip.sum()), len(d), ok
 
 
 @pytest.mark.parametrize("config", [2, 3])
@@ -478,13 +480,12 @@ def test_fast_program_rms_vs_oracle(port, config):
         chain(rays, tran, surf)
     assert rec.launches == 1 and rec.fast_launches == 1
     got = dict(zip(ALLCOLS, host(rays)))
-    rms, mx, valid, flips, nr = _rms_focal(got, want)
+    rms, mx, valid, flips, nr, ok = _rms_focal(got, want)
     print("config %d fast program: rms position error %.3e mm, max %.3e mm (valid %.3f), fp32-flat flips %d of %d"
           % (config, rms, mx, valid, flips, nr))
     assert valid > .99 and rms < 1e-10 and mx < 2e-9 and flips <= 1e-4 * nr, (rms, mx, flips)
-    for k in ("l", "m", "n", "ux", "uy", "uz"):
-        f = np.isfinite(want[k])
-        assert np.abs(got[k][f] - want[k][f]).max() < 1e-12, k
+    for k in ("l", "m", "n", "ux", "uy", "uz"):            # (a flipped ray meets the grating ~5e-5 mm aside)
+        assert np.abs(got[k][ok] - want[k][ok]).max() < 1e-12, k
     exact = dev_rays(c)
     with pxf.fused() as rec:
         chain(exact, tran, surf)
@@ -534,7 +535,9 @@ def test_fast_program_falls_back_and_covers_every_supported_op(port):
         got = to_host(t)
         for k in ALLCOLS:
             assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), (name, k)
-            f = ~np.isnan(want[k])
+            inf = np.isinf(want[k])
+            assert np.array_equal(got[k][inf], want[k][inf]), (name, k)          # x/0 = +-inf survives
+            f = np.isfinite(want[k])
             # positions of the Newton surfaces carry the reference's own along-ray jitter (~1e-8 mm for the
             # secondary); everything else agrees to rounding
             tol = 5e-8 if (short in ("wolterprimary", "woltersecondary") and k in "xyz") else 1e-9 * (1 + np.abs(want[k][f]).max())

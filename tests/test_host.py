@@ -251,3 +251,49 @@ def test_sellmeier_and_radialgrad_formulas():
     x2, y2 = x * np.cos(.01) + y * np.sin(.01), y + 8000.
     th, rr = np.arctan2(-x2, y2), np.sqrt(x2 ** 2 + y2 ** 2)
     assert np.array_equal(gx, 1.5e-5 * (np.cos(th) / rr)) and np.array_equal(gy, -1.5e-5 * (np.sin(th) / rr))
+
+
+@pytest.mark.parametrize("nmax", [1, 2, 4, 7, 10, 15])
+def test_zernike_monomial_expansion_matches_reference_zernset(port, nmax):
+    """Host side of the Cartesian Zernike kernels (no GPU): pxf_zernike_monomials expands
+    sum_i coeff_i Z_i into monomials of (x/rad, y/rad); evaluated in NumPy (Horner, as the kernel does) it
+    must equal the sum over the reference's own zernset values (specialFunctions.f95:142-232, through the
+    oracle) -- value and both gradient components -- at random points of the unit disk."""
+    import ctypes as C
+    from oracle import cases
+    from pyxfocus_amd import _lib
+    rng = np.random.default_rng(nmax)
+    nterms = (nmax + 1) * (nmax + 2) // 2
+    ro, ao = cases.noll_orders(nterms)
+    ro, ao = np.ascontiguousarray(ro, np.int32), np.ascontiguousarray(ao, np.int32)
+    coeff = np.ascontiguousarray(rng.normal(0, 1e-3, nterms))
+    N = nmax
+    out = np.zeros((N + 1) * (N + 2) // 2)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    rc = _lib.lib().pxf_zernike_monomials(coeff.ctypes.data_as(dp), ro.ctypes.data_as(ip), ao.ctypes.data_as(ip), nterms,
+                                          N, out.ctypes.data_as(dp))
+    assert rc == 0
+    off = lambda j: j * (N + 1) - j * (j - 1) // 2
+    worst = 0.
+    for _ in range(40):
+        rho, th = np.sqrt(rng.random()), rng.uniform(-np.pi, np.pi)
+        u, v = rho * np.cos(th), rho * np.sin(th)
+        s = su = sv = 0.
+        for j in range(N, -1, -1):
+            c = out[off(j):off(j) + N - j + 1]
+            p, dpv = c[0], 0.
+            for i in range(1, N - j + 1):
+                dpv = dpv * u + p
+                p = p * u + c[i]
+            sv = sv * v + s
+            s = s * v + p
+            su = su * v + dpv
+        z, dr, dt = port.zernsurf.zernset(rho, th, ro, ao)            # values, d/drho, d/dtheta of every term
+        S, Sr, St = float(coeff @ z), float(coeff @ dr), float(coeff @ dt)
+        Sx = np.cos(th) * Sr - np.sin(th) * St / rho                   # zernsurf.f95:63-66
+        Sy = np.sin(th) * Sr + np.cos(th) * St / rho
+        scale = np.abs(coeff).sum() * (1 + nmax) ** 2
+        worst = max(worst, abs(s - S) / scale, abs(su - Sx) / scale, abs(sv - Sy) / scale)
+    # relative to sum |coeff| x n^2 (the natural size of a gradient): 1e-13 up to degree 10 (the kernels'
+    # Cartesian range), 1e-10 at 15 (not used there: orders 11..15 stay on the polar recurrences)
+    assert worst < (1e-13 if nmax <= 10 else 1e-10), worst

@@ -23,13 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "pyxfocus_amd", "csrc", "libpxf_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
-# demangled-name prefix -> most vector registers it may spill
-VGPR_SPILL_ALLOWED = {
-    "pxf::ZernOpSel<7,": 8,          # the 36-term kernel at three waves per SIMD
-    "pxf::ZernOpSel<8,": 4,
-    "pxf::ZernOpSel<6,": 8, "pxf::ZernOpSel<5,": 8,
-    "pxf::program_zern_kernel<7,": 8,
-}
+# demangled-name prefix -> most vector registers it may spill (none: since the Zernike kernels evaluate a
+# Horner polynomial, round 2, no kernel of the library spills a vector register)
+VGPR_SPILL_ALLOWED = {}
 
 
 def _kernels():
