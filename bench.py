@@ -311,8 +311,8 @@ def bench_config3(n, steps, dev, pxf, sources, tran, surf, con):
 
 def bench_config4(n, steps, dev, pxf, sources, tran, surf):
     """BASELINE config 4: 36-term Zernike sag surface (rad 50), zernsurf -> reflect -> flat, 264 B/ray.
-    fp64-VALU-bound: reports the HBM fraction AND the fp64 rate against the 78.6 TF vector peak
-    (flops per ray from the SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 counters of profiles/pmc_flops.json)."""
+    Reports the HBM fraction AND the fp64 rate against the 78.6 TF vector peak (flops per ray from the
+    SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 counters of profiles/pmc_flops.json)."""
     from oracle import cases
     par4 = wl.config4_setup(surf.zmodes)
 
@@ -346,15 +346,18 @@ def bench_config4(n, steps, dev, pxf, sources, tran, surf):
     tot = sum(k["avg_ms"] for k in kern)
     z = kern[0]
     f = float(np.mean(fms))
-    roof = {"bound": "fp64-valu", "kernel": "zernsurf", "hbm_achieved_GBps": z["GBps"], "hbm_peak_GBps": HBM_PEAK_GBS,
-            "hbm_frac": z["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": z["avg_ms"],
-            "algorithmic_bytes_per_launch": z["bytes_per_ray"] * n}
+    # Round 1's polar evaluation was fp64-VALU-bound (0.32 of HBM); the Horner form of round 2 is HBM-bound.
+    # Both rates are reported: HBM fraction (the bound) and the fp64 rate against the 78.6 TF vector peak.
+    roof = {"bound": "hbm", "kernel": "zernsurf", "achieved": z["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": z["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": z["avg_ms"],
+            "algorithmic_bytes_per_launch": z["bytes_per_ray"] * n,
+            "traffic": (pmc_entry("pmc_traffic.json", "config4:zernsurf", n) or {}).get("hbm_bytes_per_launch")}
     fl = pmc_entry("pmc_flops.json", "config4:zernsurf", n) or pmc_entry("pmc_flops.json", "config4:zernsurf", 10 ** 8)
     if fl:
         tf = fl["fp64_flops_per_ray"] * n / (z["avg_ms"] * 1e-3) / 1e12
-        roof.update({"achieved": tf, "peak": wl.FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tf / wl.FP64_VECTOR_PEAK_TFLOPS, "fp64_flops_per_ray": fl["fp64_flops_per_ray"],
-                     "flops_source": "%s @ %s" % (fl.get("source"), fl.get("commit"))})
+        roof["fp64"] = {"achieved": tf, "peak": wl.FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / wl.FP64_VECTOR_PEAK_TFLOPS, "fp64_flops_per_ray": fl["fp64_flops_per_ray"],
+                        "flops_source": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64, %s @ %s" % (fl.get("source"), fl.get("commit"))}
 
     def cols():
         rng = np.random.default_rng(44)

@@ -477,7 +477,7 @@ int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total,
                                /* [I]TRANSFORM, REFLECT (PXF_ERANGE otherwise: run the trace as its own launch) */
 #define PXF_PROGRAM_MAX_OPS 32
 #define PXF_PROGRAM_MAX_OPS_ZERN 16
-#define PXF_PROGRAM_ZERN_MAX_ORDER 7 /* highest radial order of a FUSED Zernike trace (PXF_ERANGE above) */
+#define PXF_PROGRAM_ZERN_MAX_ORDER 15 /* highest radial order of a FUSED Zernike trace (= of any Zernike trace) */
 
 /* host-side coefficient table of a PXF_OP_TRACEZERN[OPD] operation (the arguments of pxf_tracezern) */
 typedef struct pxf_zern_args {

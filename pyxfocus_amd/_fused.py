@@ -55,7 +55,7 @@ SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5,
          "pxf_refract": (4, 5, 6, 7, 8, 9)}
 MAX_OPS = 32
 MAX_OPS_ZERN = 16      # PXF_PROGRAM_MAX_OPS_ZERN: a program around a Zernike trace
-ZERN_MAX_ORDER = 7     # PXF_PROGRAM_ZERN_MAX_ORDER: higher radial orders run as their own launch
+ZERN_MAX_ORDER = 15    # PXF_PROGRAM_ZERN_MAX_ORDER
 # what a program around a Zernike trace may hold besides the trace (pxf_program_zern.hip: zprog_supported)
 ZERN_COMPANIONS = {1, 2, 8, 9, 10}     # flat, flatopd, transform, itransform, reflect
 ZERN_CODES = {"pxf_tracezern": 23, "pxf_tracezernopd": 24}

@@ -1,10 +1,10 @@
 // pxf_program_zern.hip -- fused ray program AROUND a Zernike trace (PXF_OP_TRACEZERN[OPD]).
 //
 // BASELINE config 4 is  source -> zernsurf -> reflect -> flat : as three launches it moves
-// 96 + 72 + 96 B/ray; with the ray held in registers it is bounded by the Zernike kernel's own fp64
-// work.  The Zernike operation brings a coefficient table (LDS, staged once per workgroup) and a
-// large register footprint, so programs that contain one run in this separate kernel -- one ray per
-// thread, like the stand-alone Zernike kernel -- and the common programs keep their small one.
+// 96 + 72 + 96 B/ray; with the ray held in registers it moves 120.  The Zernike operation brings a
+// coefficient table (LDS, staged once per workgroup; held in registers across the Newton loop up to
+// degree 10), so programs that contain one run in this separate kernel -- two rays per thread, like
+// the stand-alone Zernike kernel -- and the common programs keep their small register budget.
 //
 // This translation unit is compiled -ffp-contract=off like every bit-exact Op needs; the Zernike
 // evaluation asks for FMA contraction in its own function bodies (pxf_ops_zernike.h).  The other
@@ -15,7 +15,7 @@
 namespace pxf {
 
 #ifndef PXF_ZPROG_WAVES
-#define PXF_ZPROG_WAVES 3
+#define PXF_ZPROG_WAVES 2   // <= 256 registers per lane (no AGPRs: pxf_ops_zernike.h)
 #endif
 constexpr int kMaxOpsZ = PXF_PROGRAM_MAX_OPS_ZERN;
 constexpr int kZernFusedMaxN = PXF_PROGRAM_ZERN_MAX_ORDER;
@@ -29,12 +29,9 @@ struct ProgramZ {  // a Program cut to the operation count a Zernike program may
 static_assert(sizeof(ProgramZ) + sizeof(ZernOp<kZernFusedMaxN, false>) + sizeof(Cols) + 64 <= 4096,
               "program + Zernike table must fit the kernel-argument segment");
 
-// (three waves per SIMD like the stand-alone order-7 kernel: 168 registers, eight of them spilled.  With
-// the library's full interpreter step in the kernel the same request cost 340 bytes of spills and two
-// waves were faster; with the lean step it is 5.4 ms for config 4 against 6.8 ms at two waves.)
 // The operations a Zernike program may hold besides the trace itself: the frame changes, reflect, flat.
-// The full interpreter step (pxf_program.h exec_op) inlines every Op of the library; its register and
-// scalar footprint on top of the Zernike evaluation pushed this kernel to two waves per SIMD with spills.
+// (The full interpreter step of pxf_program.h inlines every Op of the library: a register and scalar
+// footprint this kernel does not need.)
 __host__ __device__ constexpr bool zprog_supported(int code)
 {
     return code == PXF_OP_FLAT || code == PXF_OP_FLATOPD || code == PXF_OP_TRANSFORM || code == PXF_OP_ITRANSFORM ||
@@ -59,48 +56,56 @@ __device__ __forceinline__ void exec_op_lite(int code, int flags, const double *
     }
 }
 
-template <int NMAX, bool NT, bool ANYMASK>
-__global__ __launch_bounds__(kBlock, PXF_ZPROG_WAVES) void program_zern_kernel(Cols c, int64_t num, ProgramZ pg,
-                                                                                      ZernOp<NMAX, false> zop, int iz)
+template <int NMAX, int V, bool NT>
+__global__ __launch_bounds__(kBlock, PXF_ZPROG_WAVES) void program_zern_kernel(Cols c, int64_t first, int64_t nvec,
+                                                                                      ProgramZ pg, ZernOp<NMAX, false> zop, int iz)
 {
-    constexpr int V = 1;
     zop.prologue();  // Zernike table -> LDS (contains the barrier: before any thread may exit)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t vv = (int64_t)blockIdx.x * kBlock + threadIdx.x; vv < num; vv += stride) {
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const int64_t vv = first + v;
         Ray r[V];
 #pragma unroll
         for (int col = 0; col < 10; col++) {
             if (pg.load & B(col)) {  // wave-uniform
                 double t[V];
                 load_col<V, NT>(c.p[col], vv, t);
-                r[0].c[col] = t[0];
+#pragma unroll
+                for (int k = 0; k < V; k++) r[k].c[col] = t[k];
             }
         }
+        bool sel[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) sel[k] = true;
         for (int i = 0; i < pg.nops; i++) {
             const ProgOp &o = pg.op[i];
-            bool sel[V] = {true};
-            Ray keep[ANYMASK ? V : 1];
-            const bool masked = ANYMASK && o.mask != nullptr;
-            if (masked) {
-                sel[0] = o.mask[vv] != 0;
-                keep[0] = r[0];
-            }
             if (i == iz) {
                 unsigned wm[V];
-                const double opd_in = r[0].c[OPD];  // plain tracezern does not touch the opd column, which
-                if (!zop.has_opd) r[0].c[OPD] = 0.;   // may be live in the program (ZernOp::apply adds t*nr)
+                double opd_in[V];  // plain tracezern does not touch the opd column, which may be live in the
+#pragma unroll             // program (ZernOp::apply adds t*nr to it)
+                for (int k = 0; k < V; k++) {
+                    opd_in[k] = r[k].c[OPD];
+                    if (!zop.has_opd) r[k].c[OPD] = 0.;
+                }
                 zop.template apply<V>(r, sel, wm);
-                if (!zop.has_opd) r[0].c[OPD] = opd_in;
+                if (!zop.has_opd) {
+#pragma unroll
+                    for (int k = 0; k < V; k++) r[k].c[OPD] = opd_in[k];
+                }
             } else {
                 exec_op_lite<V>(o.code, o.flags, o.p, r, sel);
             }
-            if (masked && !sel[0]) r[0] = keep[0];  // unselected rays keep every register
         }
 #pragma unroll
         for (int col = 0; col < 10; col++) {
             if (pg.store & B(col)) {
-                double t[V] = {r[0].c[col]};
-                bool w[V] = {true};
+                double t[V];
+                bool w[V];
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    t[k] = r[k].c[col];
+                    w[k] = true;
+                }
                 store_col<V, NT>(c.p[col], vv, t, w);
             }
         }
@@ -117,16 +122,24 @@ static int launch_zern_nmax(const ProgramZ &pz, int iz, const ZernTab &tab, cons
     zop.nr = pz.op[iz].p[1];
     zop.has_opd = pz.op[iz].code == PXF_OP_TRACEZERNOPD;
     hipStream_t s = (hipStream_t)stream;
-    const int g = grid_for(num);
-    // no `ind=` masks in a Zernike program: the saved copy of the ray that a masked operation needs would
-    // push this kernel deep into register spills (46 vector + 90 scalar registers) -- the caller runs
-    // such a sequence as separate launches
+    // no `ind=` masks in a Zernike program (the caller runs such a sequence as separate launches)
     for (int i = 0; i < pz.nops; i++)
         if (pz.op[i].mask != nullptr || !zprog_supported(pz.op[i].code)) return PXF_ERANGE;
-    if (use_nt(num))
-        hipLaunchKernelGGL((program_zern_kernel<NMAX, true, false>), dim3(g), dim3(kBlock), 0, s, c, num, pz, zop, iz);
-    else
-        hipLaunchKernelGGL((program_zern_kernel<NMAX, false, false>), dim3(g), dim3(kBlock), 0, s, c, num, pz, zop, iz);
+    bool aligned = true;
+    for (int col = 0; col < 10; col++)
+        if (((pz.load | pz.store) & B(col)) && ((uintptr_t)c.p[col] & 15)) aligned = false;
+    const bool nt = use_nt(num);
+    const int64_t nvec2 = aligned ? num / 2 : 0;
+    if (nvec2 > 0) {
+        if (nt) hipLaunchKernelGGL((program_zern_kernel<NMAX, 2, true>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pz, zop, iz);
+        else hipLaunchKernelGGL((program_zern_kernel<NMAX, 2, false>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pz, zop, iz);
+    }
+    const int64_t done = nvec2 * 2;
+    if (done < num) {
+        const int64_t rest = num - done;
+        if (nt) hipLaunchKernelGGL((program_zern_kernel<NMAX, 1, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pz, zop, iz);
+        else hipLaunchKernelGGL((program_zern_kernel<NMAX, 1, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pz, zop, iz);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }
@@ -145,12 +158,11 @@ int launch_program_zern(const Program &pg, int iz, const pxf_zern_args_t *za, co
     pz.store = pg.store;
     for (int i = 0; i < pg.nops; i++) pz.op[i] = pg.op[i];
     pz.op[iz].aux = nullptr;  // (a host pointer: never dereferenced on the device)
-    // Instantiated for radial orders <= 4 and <= 7 (36 terms).  Higher orders are not offered as fused
-    // programs: with the interpreter's operations in the same kernel they exhaust both register files
-    // (SGPRs spilled while no VGPR is free), the regime in which stand-alone order-11..15 kernels were
-    // seen to return wrong results before their constants moved to LDS (pxf_ops_zernike.h).  The caller
-    // runs such a trace as its own launch (PXF_ERANGE).
+    // Instantiated for radial orders <= 4, <= 7 (36 terms), <= 10 and <= 15; a table of lower order runs
+    // in the next instantiation above it with zero high coefficients.
     if (nmax <= 4) return launch_zern_nmax<4>(pz, iz, tab, c, num, stream);
+    if (nmax <= 7) return launch_zern_nmax<7>(pz, iz, tab, c, num, stream);
+    if (nmax <= 10) return launch_zern_nmax<10>(pz, iz, tab, c, num, stream);
     if (nmax <= kZernFusedMaxN) return launch_zern_nmax<kZernFusedMaxN>(pz, iz, tab, c, num, stream);
     return PXF_ERANGE;
 }

@@ -299,7 +299,7 @@ def test_fused_program_around_a_zernike_trace(nterms, nr):
     """BASELINE config 4 as ONE launch: transform -> zernsurf -> reflect -> flat inside fused() equals
     the four stand-alone launches (the Zernike arithmetic is tolerance-parity, the other operations
     are the same bits given the same inputs), for the instantiated order ranges and the OPD variant;
-    radial orders above 7 are not fused (their trace stays its own launch inside the block)."""
+    every radial order is fused (instantiations for orders <= 4, 7, 10, 15)."""
     import pyxfocus_amd as pxf
     import pyxfocus_amd.surfaces as surf
     import pyxfocus_amd.transformations as tran
@@ -319,10 +319,7 @@ def test_fused_program_around_a_zernike_trace(nterms, nr):
     chain(a)
     with pxf.fused() as rec:
         chain(b)
-    if max(ro) <= 7:
-        assert rec.launches == 1 and rec.fused_ops == 4
-    else:           # orders above 7 are traced by their own launch between two programs
-        assert rec.launches == 2 and rec.fused_ops == 3
+    assert rec.launches == 1 and rec.fused_ops == 4
     for k, u, v in zip(ALLCOLS, a, b):
         u, v = u.cpu().numpy(), v.cpu().numpy()
         assert np.array_equal(np.isnan(u), np.isnan(v)), k

@@ -135,7 +135,7 @@ def zernike_order_check(port, nmax, masked=False, n=3001):
     with pxf.fused() as rec:
         native.zernsurf.tracezern(*[t[k] for k in nine], coeff, ro, ao, 50., **kw)
     if not masked:
-        assert rec.launches == (1 if nmax <= 7 else 0)          # orders above 7 are not fused
+        assert rec.launches == 1
     check(to_host(t), want, c, "tracezern fused")
     want = oracle(port.zernsurf.tracezernopd, c, ALLCOLS, coeff, ro, ao, 50., 1.4)
     t = to_dev(c)
