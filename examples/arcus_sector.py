@@ -139,6 +139,80 @@ def defineSPOaperture(api, N, offX=0., offY=0., gap=GAP, rows=range(8), modules_
     return rays, weights, focVec[-1], lmax, coords
 
 
+def petal_layout(rows=range(8), modules_per_row=None, shell_stride=1):
+    """Every shell of every module of the petal, in the order defineSPOaperture traces them: a list of
+    (R, primary length L, focal length, azimuthal span, module angle [rad], geometric area)."""
+    out = []
+    for i in rows:
+        R, L, focVec, spanv, area = module_geometry(i, shell_stride)
+        angs = ANG[i] if modules_per_row is None else ANG[i][:modules_per_row]
+        for a in angs:
+            out.extend((float(R[k]), float(L[k]), float(focVec[k]), float(spanv[k]), a * np.pi / 180, float(area[k]))
+                       for k in range(len(R)))
+    return out
+
+
+def defineSPOaperture_segmented(N, gap=GAP, rows=range(8), modules_per_row=None, shell_stride=1, source="philox",
+                                seed=0, fast=False, rays=None):
+    """defineSPOaperture (offX = offY = 0) the MI355X way: every shell of the petal is one SEGMENT of N rays
+    of ONE bundle; the shells' sources are one launch (`sources.segments`, device Philox), their SPO pair
+    -- frame rotation, spoPrimary, reflect, graze angle, spoSecondary, reflect, graze angle, move to the
+    focus -- is ONE launch (`compile_segments`: per-shell constants staged in LDS, the two graze-angle
+    columns written by the same kernel), and the move to the grating plane + flat is one more.  The
+    reference (sector.py:556) loops over the 2732 shells in Python.  N must be even and >= 172.
+
+    source="numpy": the shells' rays are drawn on the host from the np.random stream in the reference's
+    order (parity runs); fast=True: the opt-in tolerance-mode kernel.  Returns what defineSPOaperture
+    returns, plus the compiled program (re-runnable on a refilled bundle)."""
+    import torch
+    import pyxfocus_amd as pxf
+    api = Api.amd()
+    shells = petal_layout(rows, modules_per_row, shell_stride)
+    ns = len(shells)
+    n = ns * N
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if rays is None:
+        buf = torch.empty((10, n), dtype=torch.float64, device=dev)
+        rays = [buf[i] for i in range(10)]
+    if source == "philox":
+        api.sources.segments("subannulus", [(sh[0], sh[0] + PORE, sh[3], -1.) for sh in shells], N, out=rays, seed=seed)
+    else:
+        host = np.zeros((10, n))
+        for k, sh in enumerate(shells):            # sources.subannulus(R, R+d, span, N, zhat=-1) per shell
+            rho = np.sqrt(sh[0] ** 2 + np.random.rand(N) * ((sh[0] + PORE) ** 2 - sh[0] ** 2))
+            theta = np.random.rand(N) * sh[3] - sh[3] / 2.
+            host[1, k * N:(k + 1) * N], host[2, k * N:(k + 1) * N] = rho * np.cos(theta), rho * np.sin(theta)
+            host[6, k * N:(k + 1) * N] = -1.
+        for i in range(10):
+            rays[i].copy_(torch.from_numpy(host[i]))
+    g1 = torch.empty(n, dtype=torch.float64, device=dev)
+    g2 = torch.empty(n, dtype=torch.float64, device=dev)
+
+    def shell(sl, R, foc, ang, o1, o2):
+        api.tran.transform(sl, 0, 0, 0, 0, 0, ang)
+        api.surf.spoPrimary(sl, R, foc)
+        api.tran.reflect(sl)
+        api.anal.grazeAngle(sl, out=o1)
+        api.surf.spoSecondary(sl, R, foc)
+        api.tran.reflect(sl)
+        api.anal.grazeAngle(sl, out=o2)
+        api.tran.transform(sl, 0, 0, -foc, 0, 0, 0)
+
+    prog = pxf.compile_segments(rays, N, shell, [(sh[0], sh[2], sh[4], g1[k * N:(k + 1) * N], g2[k * N:(k + 1) * N])
+                                                 for k, sh in enumerate(shells)], fast=fast)
+    prog.run()
+    for j in (0, 7, 8, 9):                               # traceSPO collects columns 1..6 only (:622-626)
+        rays[j].zero_()
+    weights = api.asarray(np.repeat([sh[5] / N for sh in shells], N), rays[1]) * reflectivity(api, g1) * reflectivity(api, g2)
+    coords = api.tran.newCoords()
+    lmax = module_geometry(list(rows)[0], shell_stride)[1].max()               # L.max() of the first row (:432-433)
+    R, L, focVec, spanv, area = module_geometry(list(rows)[-1], shell_stride)
+    with pxf.fused(fast=fast):
+        api.tran.transform(rays, 0, 0, focVec[-1] - (L.max() + gap + GRATLEN), 0, 0, 0, coords=coords)
+        api.surf.flat(rays)
+    return rays, weights, focVec[-1], lmax, coords, prog
+
+
 def gratArray(api, rays, outerrad, hubdist, angle, inc, l=GRATLEN, weights=None, order=0, blazeYaw=0., wave=1.,
               offX=0., coords=None, maxiter=10000, focus_kw=None):
     """Rays leaving the petal -> fanned grating array rotated about the hub -> back to the frame of

@@ -472,6 +472,9 @@ int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total,
 #define PXF_OP_GRAT 21         /* a: d, order*wave ; aux (optional) = per-ray order*wave column */
 #define PXF_OP_REFRACT 22      /* a: n1, n2 */
 #define PXF_OP_TRACEZERN 23    /* a: rad      ; aux = (const double *)&pxf_zern_args_t on the HOST */
+#define PXF_OP_INDANGLE 25     /* a: graze (0: acos(d.u), 1: pi/2 - acos(d.u)) ; aux = OUTPUT column (analyses.py:164-187): */
+                               /* the angle of every ray as it stands at that point of the program, e.g. the two  */
+                               /* graze angles behind the reflectivity weights of sector.py:592-612               */
 #define PXF_OP_TRACEZERNOPD 24 /* a: rad, nr  ; aux as above.  At most ONE Zernike operation per program, */
                                /* such a program holds at most PXF_PROGRAM_MAX_OPS_ZERN operations, unmasked, out of FLAT[OPD], */
                                /* [I]TRANSFORM, REFLECT (PXF_ERANGE otherwise: run the trace as its own launch) */

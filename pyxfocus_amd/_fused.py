@@ -40,7 +40,7 @@ OPCODES = {"pxf_flat": 1, "pxf_flatopd": 2, "pxf_conic": 3, "pxf_conicopd": 4, "
            "pxf_wolterprimaryopd": 6, "pxf_woltersecondary": 7, "pxf_transform": 8, "pxf_itransform": 9,
            "pxf_reflect": 10, "pxf_radgrat": 11, "pxf_radgratw": 12, "pxf_spocone": 13, "pxf_tracesphere": 14,
            "pxf_tracesphereopd": 15, "pxf_tracecyl": 16, "pxf_tracecylopd": 17, "pxf_cylconic": 18,
-           "pxf_paraxial": 19, "pxf_paraxialy": 20, "pxf_grat": 21, "pxf_refract": 22}
+           "pxf_paraxial": 19, "pxf_paraxialy": 20, "pxf_grat": 21, "pxf_refract": 22, "pxf_indangle": 25}
 # bundle slots (opd=0, x=1 ... uz=9) of the columns each entry point takes, in call order
 SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5, 6, 7, 8, 9, 0),
          "pxf_conic": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_conicopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9),
@@ -52,7 +52,7 @@ SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5,
          "pxf_tracesphereopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_tracecyl": (1, 2, 3, 4, 5, 6, 7, 8, 9),
          "pxf_tracecylopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_cylconic": (1, 2, 3, 4, 5, 6, 7, 8, 9),
          "pxf_paraxial": (1, 2, 4, 5), "pxf_paraxialy": (2, 5), "pxf_grat": (4, 5, 6, -1),
-         "pxf_refract": (4, 5, 6, 7, 8, 9)}
+         "pxf_refract": (4, 5, 6, 7, 8, 9), "pxf_indangle": (4, 5, 6, 7, 8, 9, -1)}
 MAX_OPS = 32
 MAX_OPS_ZERN = 16      # PXF_PROGRAM_MAX_OPS_ZERN: a program around a Zernike trace
 ZERN_MAX_ORDER = 15    # PXF_PROGRAM_ZERN_MAX_ORDER
@@ -72,7 +72,8 @@ class PxfOp(C.Structure):
                 ("a", C.c_double * 6)]
 
 
-FAST_CODES = {1, 5, 7, 8, 9, 10, 11, 13}     # what pxf_program_run_fast accepts (pxf_program_fast.hip)
+FAST_CODES = {1, 5, 7, 8, 9, 10, 11, 13, 25}     # what pxf_program_run_fast accepts (pxf_program_fast.hip)
+AUX_OUT_CODES = {25}                              # operations whose aux is an OUTPUT column (indAngle)
 
 
 class _Recorder:
@@ -168,7 +169,8 @@ class _Recorder:
         ptrs = (C.c_void_p * 10)(*[(p or None) for p in self.ptrs])
         dev = self.dev
         from .native import _stream          # (native imports this module)
-        fast = self.fast and all(o.code in FAST_CODES and not o.mask and not o.aux for o in self.ops)
+        fast = self.fast and all(o.code in FAST_CODES and not o.mask and (not o.aux or o.code in AUX_OUT_CODES)
+                                 for o in self.ops)
         run = _lib.lib().pxf_program_run_fast if fast else _lib.lib().pxf_program_run
         if dev.index == torch.cuda.current_device():    # the common case: skip the device guard
             rc = run(ops, len(self.ops), ptrs, self.num, _stream(dev))
@@ -223,7 +225,8 @@ class SegmentedProgram:
     often as needed (e.g. after refilling the bundle from a segmented source)."""
 
     def __init__(self, rays, rays_per_seg, ops, table, keep, fast=False):
-        self.fast = bool(fast) and all(o.code in FAST_CODES for o in ops)
+        self.fast = bool(fast) and all(o.code in FAST_CODES and not o.mask and (not o.aux or o.code in AUX_OUT_CODES)
+                                       for o in ops)
         self.rays = list(rays)
         self.rps = int(rays_per_seg)
         self.ops = ops                  # ctypes array of PxfOp (codes, masks, aux)
@@ -254,7 +257,7 @@ def compile_segments(rays, rays_per_seg, fn, params, fast=False):
     if nseg * rps != num:
         raise ValueError("compile_segments: len(params) * rays_per_seg must equal the bundle length")
     h = _lib.lib()
-    rows, codes0, ops0 = [], None, None
+    rows, codes0, ops0, aux0, keep_all = [], None, None, None, []
     if getattr(_tls, "rec", None) is not None:
         raise _lib.PxfError("compile_segments cannot be called inside a fused() block")
     for s_, par in enumerate(params):
@@ -267,8 +270,16 @@ def compile_segments(rays, rays_per_seg, fn, params, fast=False):
             _tls.rec = None
         if rec.launches or not rec.ops:
             raise _lib.PxfError("compile_segments: the segment function issued a call that cannot be fused")
-        if any(o.mask or o.aux for o in rec.ops):
-            raise _lib.PxfError("compile_segments: ind= masks / per-ray columns are not supported per segment")
+        if any(o.mask or (o.aux and o.code not in AUX_OUT_CODES) for o in rec.ops):
+            raise _lib.PxfError("compile_segments: ind= masks / per-ray input columns are not supported per segment")
+        # output columns (indAngle(..., out=)): segment s must write the s-th slice of ONE bundle-long column
+        auxs = [o.aux for o in rec.ops]
+        if s_ == 0:
+            aux0 = auxs
+        elif any((a or 0) != ((b or 0) + 8 * s_ * rps if b else 0) for a, b in zip(auxs, aux0)):
+            raise _lib.PxfError("compile_segments: out= of segment %d is not the slice [s*rays_per_seg, ...) of the "
+                                "column segment 0 writes" % s_)
+        keep_all.extend(rec.keep)
         arr = (PxfOp * len(rec.ops))(*rec.ops)
         out = (C.c_double * (9 * len(rec.ops)))()
         nl = C.c_int32()
@@ -280,7 +291,7 @@ def compile_segments(rays, rays_per_seg, fn, params, fast=False):
             raise _lib.PxfError("compile_segments: segment %d issues a different operation sequence" % s_)
         rows.append(np.frombuffer(out, dtype=np.float64, count=9 * nlive).copy())
     table = torch.from_numpy(np.stack(rows).reshape(nseg, nlive, 9)).to(rays[1].device)
-    return SegmentedProgram(rays, rps, ops0, table, None, fast=fast)
+    return SegmentedProgram(rays, rps, ops0, table, keep_all, fast=fast)
 
 
 def plan(ops):

@@ -364,15 +364,30 @@ def analyticXPlane(rays, weights=None, group=None):
     return -bx / ax
 
 
-def indAngle(rays, ind=None, normal=None, _graze=0):
+def indAngle(rays, ind=None, normal=None, _graze=0, out=None):
     """Incidence angle of the rays with either the current or a specified surface normal
-    (analyses.py:164-182).  Returns a device tensor (of the `ind`-selected rays if ind is given)."""
-    fused.flush()
+    (analyses.py:164-182).  Returns a device tensor (of the `ind`-selected rays if ind is given).
+
+    Inside a ``pyxfocus_amd.fused()`` block (or a ``compile_segments`` function) a plain call -- no `ind`, no
+    `normal` -- is RECORDED as a program operation: the angles of the rays as they stand at that point
+    of the trace are written by the fused kernel itself, and the returned tensor is valid once the block has
+    run.  ``out=`` (an addition): the column to fill; in a segmented program pass the segment's slice of
+    one bundle-long column."""
     l, m, n, ux, uy, uz = rays[4:10]
     num, dev = native._check_cols((l, m, n, ux, uy, uz), "indAngle")
+    if out is None:
+        out = torch.empty_like(l)
+    rec = fused.active()
+    if rec is not None and ind is None and normal is None and num:
+        cols = (l, m, n, ux, uy, uz, out)
+        if rec.try_add("pxf_indangle", cols, (float(_graze),), None):
+            return out
+        rec.flush()
+        if rec.try_add("pxf_indangle", cols, (float(_graze),), None):
+            return out
+    fused.flush()
     if normal is not None:
         ux, uy, uz = [torch.full_like(l, float(v)) for v in normal]
-    out = torch.empty_like(l)
     with torch.cuda.device(dev):
         rc = _lib.lib().pxf_indangle(l.data_ptr(), m.data_ptr(), n.data_ptr(), ux.data_ptr(), uy.data_ptr(),
                                      uz.data_ptr(), out.data_ptr(), num, _graze, native._stream(dev))
@@ -385,6 +400,6 @@ def indAngle(rays, ind=None, normal=None, _graze=0):
     return out[sel.to(dev)]
 
 
-def grazeAngle(rays, ind=None):
-    """Graze angle of the rays with the current surface normal (analyses.py:184-187)."""
-    return indAngle(rays, ind=ind, _graze=1)
+def grazeAngle(rays, ind=None, out=None):
+    """Graze angle of the rays with the current surface normal (analyses.py:184-187); `out=` as indAngle."""
+    return indAngle(rays, ind=ind, _graze=1, out=out)

@@ -273,4 +273,24 @@ inline void radgrat_consts(double &S, double &C)
     C = cos(pi32 / 2);
 }
 
+// indAngle / grazeAngle : analyses.py:164-187.  R l m n ux uy uz  W out  = 56 B/ray.  Shared by pxf_indangle
+// and the program operation PXF_OP_INDANGLE (same arithmetic, same bits).
+struct IndAngleOp {
+    PXF_OP_DEFAULTS
+    static constexpr unsigned RD = DIR | NRM;
+    static constexpr unsigned WR = B(AUX);
+    int graze;
+    template <int V>
+    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
+    {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const double *c = r[k].c;
+            const double a = acos(c[L] * c[UX] + c[M] * c[UY] + c[N] * c[UZ]);
+            r[k].c[AUX] = graze ? 3.141592653589793 / 2 - a : a;
+            wm[k] = WR;
+        }
+    }
+};
+
 }  // namespace pxf

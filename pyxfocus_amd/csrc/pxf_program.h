@@ -85,6 +85,14 @@ __device__ __forceinline__ void exec_op(int code, int flags, const double *__res
             }
             break;
         case PXF_OP_REFRACT: run_op(RefractOp{P[0], P[1]}, r, sel); break;
+        case PXF_OP_INDANGLE: {  // an OUTPUT column: the angle of each ray as it stands here
+            run_op(IndAngleOp{(int)P[0]}, r, sel);
+            double t[V];
+#pragma unroll
+            for (int k = 0; k < V; k++) t[k] = r[k].c[AUX];
+            store_col<V, NT>(const_cast<double *>(aux), vv, t, sel);
+            break;
+        }
         default: break;
     }
 }

@@ -163,6 +163,7 @@ struct Micro {
     int op;               // index into the op list
     int group;            // transform group bit, 0 otherwise
     bool live;
+    bool side;            // writes outside the bundle (an output column): never dead
 };
 
 int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, int *zern_op)
@@ -184,7 +185,7 @@ int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, i
                 wmaybe |= wa;
                 wa = 0;
             }
-            mi[nm++] = Micro{rd, wa, wmaybe, i, group, true};
+            mi[nm++] = Micro{rd, wa, wmaybe, i, group, true, false};
         };
         switch (u.code) {
             case PXF_OP_FLAT: add(POS | DIR, POS | NRM, 0, 0); break;
@@ -291,6 +292,12 @@ int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, i
                 o.p[1] = u.a[1];
                 add(DIR | NRM, DIR | NRM, 0, 0);
                 break;
+            case PXF_OP_INDANGLE:
+                if (!u.aux) return PXF_EINVAL;
+                o.p[0] = u.a[0] != 0. ? 1. : 0.;
+                add(DIR | NRM, 0, 0, 0);
+                mi[nm - 1].side = true;
+                break;
             case PXF_OP_TRACEZERN:
             case PXF_OP_TRACEZERNOPD: {
                 const bool wopd = u.code == PXF_OP_TRACEZERNOPD;
@@ -309,7 +316,7 @@ int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, i
     int dead = 0;
     for (int j = nm - 1; j >= 0; j--) {
         Micro &m = mi[j];
-        if (((m.wa | m.wm) & live) == 0) {
+        if (((m.wa | m.wm) & live) == 0 && !m.side) {
             m.live = false;
             dead++;
             continue;

@@ -26,7 +26,7 @@
 // evaluation that is not bit-identical lands inside that jitter and nowhere nearer.
 //
 // Supported operations: flat, transform, itransform, reflect, wolterprimary, woltersecondary, radgrat,
-// spoCone -- unmasked, no OPD variants.  Anything else: PXF_ERANGE (the caller falls back to the exact
+// spoCone, indAngle (output column) -- unmasked, no OPD variants.  Anything else: PXF_ERANGE (the caller falls back to the exact
 // kernel).  Segmented bundles (per-shell parameter blocks) are supported the same way as in the
 // exact kernel.
 #include <stdlib.h>
@@ -252,10 +252,23 @@ __device__ __forceinline__ void fast_spocone(const double *__restrict__ P, Ray (
     }
 }
 
-template <int V>
-__device__ __forceinline__ void exec_fast(int code, int flags, const double *__restrict__ P, Ray (&r)[V])
+template <int V, bool NT>
+__device__ __forceinline__ void exec_fast(int code, int flags, const double *__restrict__ P, const double *aux,
+                                          int64_t vv, Ray (&r)[V])
 {
     switch (code) {
+        case PXF_OP_INDANGLE: {  // diagnostic output column: the library's own IndAngleOp (ocml acos)
+            bool sel[V];
+            unsigned wm[V];
+            double t[V];
+#pragma unroll
+            for (int k = 0; k < V; k++) sel[k] = true;
+            IndAngleOp{(int)P[0]}.template apply<V>(r, sel, wm);
+#pragma unroll
+            for (int k = 0; k < V; k++) t[k] = r[k].c[AUX];
+            store_col<V, NT>(const_cast<double *>(aux), vv, t, sel);
+            break;
+        }
         case PXF_OP_FLAT: fast_flat<V>(r); break;
         case PXF_OP_WOLTERPRIMARY: fast_wolterprimary<V>(P, r); break;
         case PXF_OP_WOLTERSECONDARY: fast_woltersecondary<V>(P, r); break;
@@ -272,8 +285,9 @@ static bool fast_supported(const Program &pg)
 {
     for (int i = 0; i < pg.nops; i++) {
         const ProgOp &o = pg.op[i];
-        if (o.mask || o.aux) return false;
+        if (o.mask || (o.aux && o.code != PXF_OP_INDANGLE)) return false;
         switch (o.code) {
+            case PXF_OP_INDANGLE:
             case PXF_OP_FLAT:
             case PXF_OP_WOLTERPRIMARY:
             case PXF_OP_WOLTERSECONDARY:
@@ -304,7 +318,8 @@ __global__ __launch_bounds__(kBlock) void program_fast_kernel(Cols c, int64_t fi
                 for (int k = 0; k < V; k++) r[k].c[col] = t[k];
             }
         }
-        for (int i = 0; i < pg.nops; i++) exec_fast<V>(pg.op[i].code, pg.op[i].flags, pg.op[i].p, r);
+        for (int i = 0; i < pg.nops; i++)
+            exec_fast<V, NT>(pg.op[i].code, pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r);
 #pragma unroll
         for (int col = 0; col < 10; col++) {
             if (pg.store & B(col)) {
@@ -360,7 +375,8 @@ __global__ __launch_bounds__(kBlock) void program_fast_seg_kernel(Cols c, int64_
                     for (int k = 0; k < V; k++) r[k].c[col] = t[k];
                 }
             }
-            for (int i = 0; i < pg.nops; i++) exec_fast<V>(pg.op[i].code, pg.op[i].flags, &s_par[sb][i][0], r);
+            for (int i = 0; i < pg.nops; i++)
+                exec_fast<V, NT>(pg.op[i].code, pg.op[i].flags, &s_par[sb][i][0], pg.op[i].aux, vv, r);
 #pragma unroll
             for (int col = 0; col < 10; col++) {
                 if (pg.store & B(col)) {
@@ -402,6 +418,8 @@ int pxf_program_run_fast(const pxf_op_t *ops, int32_t nops, double *const *cols,
             if ((uintptr_t)cols[col] & 15) aligned = false;
         }
     }
+    for (int i = 0; i < pg.nops; i++)
+        if (pg.op[i].aux && ((uintptr_t)pg.op[i].aux & 15)) aligned = false;
     hipStream_t s = (hipStream_t)stream;
     const bool nt = use_nt(num);
     const int64_t nvec2 = aligned ? num / 2 : 0;
@@ -439,6 +457,8 @@ int pxf_program_run_segments_fast(const pxf_op_t *ops, int32_t nops, const doubl
             if ((uintptr_t)cols[col] & 15) return PXF_EINVAL;
         }
     }
+    for (int i = 0; i < pg.nops; i++)
+        if (pg.op[i].aux && ((uintptr_t)pg.op[i].aux & 15)) return PXF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int64_t nvec = num / 2;
     FastSegInfo sg{seg_params_dev, rays_per_seg, nseg};

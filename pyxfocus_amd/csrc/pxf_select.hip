@@ -16,6 +16,7 @@
 #include <stddef.h>
 
 #include "pxf_kernel.h"
+#include "pxf_ops_transforms.h"
 
 namespace pxf {
 
@@ -162,23 +163,6 @@ struct Dist3Op {
     }
 };
 
-struct IndAngleOp {
-    PXF_OP_DEFAULTS
-    static constexpr unsigned RD = DIR | NRM;
-    static constexpr unsigned WR = B(AUX);
-    int graze;
-    template <int V>
-    __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
-    {
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            const double *c = r[k].c;
-            const double a = acos(c[L] * c[UX] + c[M] * c[UY] + c[N] * c[UZ]);
-            r[k].c[AUX] = graze ? 3.141592653589793 / 2 - a : a;
-            wm[k] = WR;
-        }
-    }
-};
 
 
 // ---- order statistics of the RADII straight from x, y in ONE pass over the rays ------------------

@@ -176,3 +176,32 @@ def test_config5_segmented_wolter_programs_equal_oracle_loop(port):
     rms, mx = _rms_pos(got, want)
     assert np.isfinite(want[1]).mean() > .9 and rms < 1e-10 and mx < 1e-9, (rms, mx)
     print("config5 (segmented Wolter-I + grating vs oracle loop): rms position error %.3e mm, max %.3e mm" % (rms, mx))
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_config5_spo_stage_segmented_equals_shell_loop(fast):
+    """The petal's SPO stage as THREE launches (segmented source / segmented SPO-pair program with the two
+    graze-angle columns written in-kernel / move + flat) against the reference-shaped Python loop over
+    shells (defineSPOaperture) on the same np.random stream: bit-identical rays in the default mode,
+    reflectivity weights to 1e-13; in the opt-in tolerance mode positions to 1e-9 mm (cone intersections
+    are closed-form: no Newton jitter, only rounding)."""
+    import arcus_sector as A
+    kw = dict(rows=(0, 2, 5), modules_per_row=2, shell_stride=7)
+    N = 180
+    np.random.seed(21)
+    a = A.defineSPOaperture(A.Api.amd(), N, **kw)
+    np.random.seed(21)
+    b = A.defineSPOaperture_segmented(N, source="numpy", fast=fast, **kw)
+    assert b[5].fast == fast
+    for k, u, v in zip(ALLCOLS, host(a[0]), host(b[0])):
+        if fast:
+            assert np.array_equal(np.isfinite(u), np.isfinite(v)), k
+            assert np.abs(u - v).max() <= 1e-9 * (1 + np.abs(u).max()), (k, np.abs(u - v).max())
+        else:
+            assert bits_equal(u, v).all(), k
+    wa, wb = a[1].cpu().numpy(), b[1].cpu().numpy()
+    assert np.abs(wa - wb).max() <= 1e-13 * np.abs(wa).max()
+    assert a[2] == b[2] and a[3] == b[3] and np.array_equal(np.array(a[4]), np.array(b[4]))
+    # device Philox source: the same distribution, shell by shell (mean radius of every shell)
+    c = A.defineSPOaperture_segmented(N, source="philox", seed=3, **kw)
+    assert np.isfinite(c[0][1].cpu().numpy()).all() and abs(float(c[1].sum()) / float(b[1].sum()) - 1) < 1e-3
