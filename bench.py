@@ -21,8 +21,10 @@ the ranks all-reduce the focal-plane moments and all-gather the focal (x,y) over
 exchange the path has -- and report its time separately.  On a box with fewer GPUs than ranks the
 ranks share the GPU(s) over gloo: a REHEARSAL of the N>1 code path, flagged as such in the line.
 
-At N=1 the line also carries `configs`: BASELINE configs 3 (two-bounce + radial grating, 1e9 rays) and
-4 (36-term Zernike surface, 1e9 rays) measured the same way, each with its own roofline.
+The line also carries `configs`: at N=1 BASELINE configs 3 (two-bounce + radial grating, 1e9 rays) and
+4 (36-term Zernike surface, 1e9 rays) measured the same way, each with its own roofline; at every N
+config 5 (Arcus-style petal: 2732 SPO shells as one segmented bundle of 1e9 rays per GPU, grating stage,
+focusY over the process group, uneven focal-plane all-gather).
 
 Prints ONE JSON line (rank 0).
 """
@@ -383,6 +385,124 @@ def bench_config4(n, steps, dev, pxf, sources, tran, surf):
             "parity_vs_checker": par}
 
 
+def bench_config5(n, steps, dev, rank, world, dist, pxf, anal, tran, surf, gratarray_rays=1e8):
+    """BASELINE config 5 -- Arcus-style multi-shell petal + gratings, this rank's share of `n` rays
+    (examples/arcus_sector.py: the call shapes of the reference's examples/arcus/sector.py).
+    (a) SPO stage, all 2732 shells as segments of one bundle: segmented device source, ONE segmented program
+        (rotate, spoPrimary, reflect, graze angle, spoSecondary, reflect, graze angle, move to focus) and the
+        move to the grating plane + flat: 3 launches; exact and opt-in tolerance mode.
+    (b) the grating stage as BASELINE words it (one radial grating: tools/workloads.grating_stage) as one program.
+    (c) focal plane: focusY(weights, group=) -> vignette -> uneven all-gather of (x, y, weight) over RCCL.
+    (d) the reference's stacked-grating WHILE loop (sector.py:685-702: masks recomputed on the host each
+        round, ~225 rounds) on a `gratarray_rays` bundle -- the faithful, launch- and pass-bound form."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import arcus_sector as A
+    shells = A.petal_layout()
+    ns = len(shells)
+    per = max(172, (n // ns) // 2 * 2)
+    n = per * ns
+    out = {"workload": "config5: Arcus petal, %d SPO shells x %d rays per GPU (segmented), grating stage, focusY, "
+                       "focal all-gather" % (ns, per), "rays_per_gpu": n, "shells": ns, "rays_per_shell": per}
+    buf = torch.empty((10, n), dtype=torch.float64, device=dev)
+    rays = [buf[i] for i in range(10)]
+    for tag, fast in (("exact", False), ("fast", True)):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        best = None
+        prog = None
+        for r in range(steps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if prog is None:
+                res = A.defineSPOaperture_segmented(per, source="philox", seed=100 + rank, fast=fast, rays=rays)
+                prog = res[5]
+                torch.cuda.synchronize()
+                out.setdefault("compile_segments_s", time.perf_counter() - t0)
+                continue
+            # steady state: refill the bundle, re-run the compiled program, move + flat
+            ev[0].record()
+            A.Api.amd().sources.segments("subannulus", [(sh[0], sh[0] + A.PORE, sh[3], -1.) for sh in shells], per,
+                                         out=rays, seed=200 + r, first_index=rank * n)
+            ev[1].record()
+            prog.run()
+            ev[2].record()
+            with pxf.fused(fast=fast):
+                tran.transform(rays, 0, 0, res[2] - (max(s_[1] for s_ in shells[-1:]) + A.GAP + A.GRATLEN), 0, 0, 0)
+                surf.flat(rays)
+            ev[3].record()
+            torch.cuda.synchronize()
+            ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+            if best is None or sum(ms) < sum(best):
+                best = ms
+        tot = sum(best)
+        out["spo_stage_" + tag] = {"ms": tot, "source_ms": best[0], "spo_pair_program_ms": best[1], "move_flat_ms": best[2],
+                                   "launches": 3, "rays_per_s": n / (tot * 1e-3),
+                                   "program_GBps": (48 + 72 + 16) * n / (best[1] * 1e-3) / 1e9}   # 6 in, 9 out, 2 angle columns
+        del prog
+    # (b) BASELINE's grating stage, one program
+    for tag, fast in (("exact", False), ("fast", True)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        keep = [c.clone() for c in rays] if tag == "exact" else None
+        e0.record()
+        with pxf.fused(fast=fast):
+            wl.grating_stage(rays, tran, surf)
+        e1.record()
+        torch.cuda.synchronize()
+        out["grating_stage_" + tag] = {"ms": e0.elapsed_time(e1), "launches": 1, "rays_per_s": n / (e0.elapsed_time(e1) * 1e-3)}
+        if keep is not None:
+            for c, k in zip(rays, keep):
+                c.copy_(k)
+            del keep
+    out["valid_fraction"] = float(torch.isfinite(rays[1]).double().mean())
+    # (c) focal plane exchange
+    grp = True if dist else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    good = torch.isfinite(rays[1]) & torch.isfinite(rays[2])
+    foc = tran.vignette(rays, good)
+    w = torch.ones_like(foc[1])
+    dz = surf.focusY(foc, weights=w, group=grp)
+    torch.cuda.synchronize()
+    out["focusY"] = {"dz_mm": dz, "ms": (time.perf_counter() - t0) * 1e3, "survivors": int(foc[1].shape[0])}
+    if dist:
+        from pyxfocus_amd import dist as pdist
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        gx, gy, gw = pdist.all_gather_focal([foc[1], foc[2], w])
+        torch.cuda.synchronize(); dist.barrier()
+        ms = (time.perf_counter() - t0) * 1e3
+        out["focal_gather"] = {"ms": ms, "rays": int(gx.shape[0]), "columns": 3,
+                               "GB_received_per_rank": 24.0 * gx.shape[0] * (world - 1) / world / 1e9}
+        out["focal_gather"]["GBps_per_rank"] = out["focal_gather"]["GB_received_per_rank"] / (ms * 1e-3)
+        out["global_hpd_mm"] = anal.hpd([None, gx, gy], weights=gw)
+        del gx, gy, gw
+    del foc, w, buf, rays
+    torch.cuda.empty_cache()
+    # (d) the faithful while-loop form on a smaller bundle
+    try:
+        np.random.seed(5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nper = max(172, (int(gratarray_rays) // ns) // 2 * 2)
+        r2, w2, minfoc, lmax, coords, _ = A.defineSPOaperture_segmented(nper, source="philox", seed=300 + rank)
+        api = A.Api.amd()
+        focp = np.dot(coords[3], [0., 0., 0., 1.])[:3]
+        hubdist = float(np.sqrt(A.OUTERRAD ** 2 + focp[2] ** 2))
+        angle = float(np.arctan(A.OUTERRAD / (minfoc - (lmax + A.GAP + A.GRATLEN))))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dz2, nrows = A.gratArray(api, r2, A.OUTERRAD, hubdist, angle, A.INC, weights=w2, order=-3, blazeYaw=A.YAW,
+                                 wave=2.4, coords=coords, focus_kw={"group": grp} if dist else None)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out["gratArray_while_loop"] = {"rays": int(r2[1].shape[0]), "grating_rows": nrows, "focusY_dz_mm": dz2,
+                                       "ms": (t2 - t1) * 1e3, "rays_per_s": r2[1].shape[0] / (t2 - t1),
+                                       "spo_stage_ms_incl_compile": (t1 - t0) * 1e3}
+    except Exception as e:
+        out["gratArray_while_loop"] = {"error": repr(e)[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,7 +513,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--configs", default=None, help="extra BASELINE configs measured into `configs` "
-                    "(comma list of 3,4; default: both at N=1, none at N>1; '' for none)")
+                    "(comma list of 3,4,5; default: all three at N=1, 5 at N>1; '' for none)")
     ap.add_argument("--config-rays", type=float, default=1e9, help="rays for configs 3 and 4")
     ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--pool-gb", type=float, default=200.0, help="HBM budget for pre-generated bundles")
@@ -575,6 +695,18 @@ def main():
     del last
     torch.cuda.empty_cache()
 
+    want = args.configs if args.configs is not None else ("3,4,5" if n_gpus == 1 else "5")
+    want = [t for t in want.split(",") if t]
+    c5 = None
+    if "5" in want:                  # every rank: the focal-plane exchange of config 5 is a collective
+        try:
+            c5 = bench_config5(int(args.config_rays), args.config_steps, dev, rank, world, dist, pxf, anal, tran, surf)
+        except Exception as e:
+            c5 = {"error": repr(e)[:300]}
+            if dist:
+                raise
+        torch.cuda.empty_cache()
+
     out = None
     if rank == 0:
         value = N * n_gpus * K / elapsed
@@ -598,9 +730,8 @@ def main():
         if dist and (args.backend != "nccl" or ndev < n_gpus):
             out["rehearsal"] = ("%d ranks share %d GPU(s), collectives over %s: exercises the N>1 code path, "
                                 "NOT a scaling measurement" % (n_gpus, ndev, args.backend))
-        want = args.configs if args.configs is not None else ("3,4" if n_gpus == 1 else "")
         cfg = {}
-        for c in [t for t in want.split(",") if t]:
+        for c in [t for t in want if t != "5"]:
             try:
                 if c == "3":
                     cfg["3"] = bench_config3(int(args.config_rays), args.config_steps, dev, pxf, sources, tran, surf, con)
@@ -609,6 +740,8 @@ def main():
             except Exception as e:
                 cfg[c] = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
+        if c5 is not None:
+            cfg["5"] = c5
         if cfg:
             out["configs"] = cfg
         if not args.no_cpu_baseline:
