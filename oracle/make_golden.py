@@ -201,6 +201,14 @@ def gold_analyses(ref, tran, anal, surf):
         blob[tag + "/grazeAngle_sel"] = anal.grazeAngle(rays, ind=sel)
         blob[tag + "/indAngle_normal"] = anal.indAngle(rays, normal=[0., .6, .8])
         blob[tag + "/indAngle_normal_sel"] = anal.indAngle(rays, ind=sel, normal=[0., .6, .8])
+        if tag == "blob":         # interpolateVec (analyses.py:189-230; scipy griddata): first 400 rays, 9 x 7 grid
+            sub = [r[:400].copy() for r in rays]
+            for meth in ("linear", "nearest", "cubic"):
+                res, dx, dy = anal.interpolateVec(sub, 4, 9, 7, method=meth)
+                blob["%s/interp/%s" % (tag, meth)] = res
+                blob["%s/interp/dxdy" % tag] = np.array([dx, dy])
+            blob["%s/interp/polar" % tag] = anal.interpolateVec(sub, 5, 8, 8, polar=True)[0]
+            blob["%s/interp/vec" % tag] = anal.interpolateVec(sub, 0, 6, 6, xr=[0., 3.], yr=[-3., 1.], interpVec=sub[1] * sub[2])[0]
         for fname in ("steerX", "steerY"):
             rr = tran.copy_rays(rays)
             coords = tran.newCoords()

@@ -311,6 +311,40 @@ def hpdY(rays, weights=None):
     return (lo + hi) * .5 * 2.
 
 
+def interpolateVec(rays, I, Nx, Ny, xr=None, yr=None, method='linear', polar=False, interpVec=None):
+    """Interpolate ray column `I` (or `interpVec`) onto an Nx x Ny grid spanning the rays' x/y extent
+    (analyses.py:189-230).  Returns (grid values, dx, dy) as NumPy objects, like the reference.
+
+    The interpolation itself is `scipy.interpolate.griddata` -- a Delaunay triangulation from a third-party
+    library the reference calls too -- and runs on the HOST on copies of the three columns involved: this is
+    post-processing of a focal plane onto a few thousand grid nodes, not a per-ray hot loop, and sharing the
+    reference's own call is what makes the result identical to it."""
+    from scipy.interpolate import griddata
+    fused.flush()
+    x = rays[1].detach().cpu().numpy()
+    y = rays[2].detach().cpu().numpy()
+    if interpVec is None:
+        interpVec = rays[I]
+    v = interpVec.detach().cpu().numpy() if isinstance(interpVec, torch.Tensor) else np.asarray(interpVec)
+    if xr is None:
+        xr = [x.min(), x.max()]
+        yr = [y.min(), y.max()]
+    gridx, gridy = np.meshgrid(np.linspace(xr[0], xr[1], Nx), np.linspace(yr[0], yr[1], Ny))
+    dx = np.diff(gridx)[0][0]
+    dy = np.diff(np.transpose(gridy))[0][0]
+    if polar is True:
+        rho_ = np.sqrt(x ** 2 + y ** 2)
+        theta1, theta2 = np.arctan2(y, x), np.arctan2(x, y)
+        rhog = np.sqrt(gridx ** 2 + gridy ** 2)
+        azg1, azg2 = rhog * np.arctan2(gridy, gridx), rhog * np.arctan2(gridx, gridy)
+        res1 = griddata((rho_, theta1 * rho_), v, (rhog, azg1), method=method)
+        res2 = griddata((rho_, theta2 * rho_), v, (rhog, azg2), method=method)
+        res = np.nanmedian([res1, res2], axis=0)
+    else:
+        res = griddata((x, y), v, (gridx, gridy), method=method)
+    return res, dx, dy
+
+
 def radialGrad(x, y, hubscale, yaw, hubdist):
     """x and y derivatives of a radial-grating phase function; hubscale = lambda / (nn/mm)
     (analyses.py:403-428, including its quirk: the yaw-rotated y2 is overwritten by y + hubdist).

@@ -104,3 +104,19 @@ def test_steer_equals_reference_transformations(golden):
             for k, r in zip(ALLCOLS, rays):
                 want = g["%s/%s/out/%s" % (tag, fname, k)]
                 assert np.abs(r.cpu().numpy() - want).max() <= 1e-11 * (1. + np.abs(want).max()), (tag, fname, k)
+
+
+def test_interpolateVec_equals_reference(golden):
+    """analyses.interpolateVec (analyses.py:189-230): the same scipy.griddata call on host copies of the
+    device columns -> the reference's grid values bit for bit (linear / nearest / cubic, polar, explicit
+    range + interpVec), same dx, dy."""
+    import pyxfocus_amd.analyses as anal
+    g = golden["analyses"]
+    rays = _dev([g["blob/in/%s" % k][:400] for k in ALLCOLS])
+    for meth in ("linear", "nearest", "cubic"):
+        res, dx, dy = anal.interpolateVec(rays, 4, 9, 7, method=meth)
+        assert np.array_equal(res, g["blob/interp/" + meth], equal_nan=True), meth
+        assert np.array_equal([dx, dy], g["blob/interp/dxdy"])
+    assert np.array_equal(anal.interpolateVec(rays, 5, 8, 8, polar=True)[0], g["blob/interp/polar"], equal_nan=True)
+    got = anal.interpolateVec(rays, 0, 6, 6, xr=[0., 3.], yr=[-3., 1.], interpVec=rays[1] * rays[2])[0]
+    assert np.array_equal(got, g["blob/interp/vec"], equal_nan=True)
