@@ -137,6 +137,9 @@ def collect(target, workload, out):
         for op, d in acc.items():
             if op in ks:
                 ks[op].setdefault("pmc", {}).update({c: sum(v) / len(v) for c, v in d.items()})
+    import shutil
+    for sub in ["trace"] + list(PMC_PASSES):          # raw CSVs are large (gpurun brings back <= 64 MiB): keep the logs only
+        shutil.rmtree(os.path.join(out, sub), ignore_errors=True)
     for op, e in ks.items():
         e["launches"] = len(e["dur_ns"])
         e["avg_ms"] = sum(e["dur_ns"]) / len(e["dur_ns"]) / 1e6
@@ -177,8 +180,10 @@ def write_tables(tag, target, ks, rays, note, launch_bytes):
     for op in ks:                                   # surface intersections: 6 columns in, 6 out
         if op.split("<")[0] in ("LLOp", "WSOp", "WolterSineOp", "ZernOpSel", "WolterPrimaryOp", "WolterSecondaryOp"):
             alg.setdefault(op, 96)
-        if op.split("<")[0] in ("program_kernel", "program_zern_kernel", "program_fast_kernel") and target != "ops":
+        if op.split("<")[0] in ("program_kernel", "program_zern_kernel", "program_fast_kernel") and target not in ("ops", "config5"):
             alg.setdefault(op, 120)                 # the configs' programs: 6 columns in, 9 out
+        if op.split("<")[0] in ("program_seg_kernel", "program_fast_seg_kernel"):
+            alg.setdefault(op, 136)                 # SPO pair: 6 in, 9 out, two graze-angle columns
     lines = ["# rocprofv3 summary `%s` / `%s`" % (tag, target), "", note, "",
              "Durations: `rocprofv3 --kernel-trace --stats`; HBM bytes: two `--pmc` passes (FETCH_SIZE x 1024 x 2 per "
              "MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE x 1024); instruction mix: `--pmc` SQ passes. "
@@ -211,7 +216,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r02")
     ap.add_argument("--commit", default="unknown")
-    ap.add_argument("--targets", default="config2,config3,config4,ops")
+    ap.add_argument("--targets", default="config2,config3,config4,config5,ops")
     ap.add_argument("--quick", action="store_true", help="1e8-ray configs 3/4 (faster passes)")
     a = ap.parse_args()
     import bench
@@ -228,6 +233,10 @@ def main():
         "config4": (py + [b, "--steps", "1", "--warmup", "0", "--rays", "1e6", "--no-cpu-baseline", "--no-fused", "--configs", "4",
                           "--config-rays", str(crays), "--config-steps", "2"], crays, wl.CONFIG4,
                     "BASELINE config 4 (36-term Zernike surface), %g rays, per call and fused (program_zern)." % crays),
+        "config5": (py + [b, "--steps", "1", "--warmup", "0", "--rays", "1e6", "--no-cpu-baseline", "--no-fused", "--configs", "5",
+                          "--config-rays", str(crays), "--config-steps", "1"], crays, [],
+                    "BASELINE config 5 share (Arcus petal: segmented source, segmented SPO-pair program exact + fast, grating "
+                    "program, focusY), %g rays; the stacked-grating while loop runs on 1e8 rays." % crays),
         "ops": (py + [os.path.join(ROOT, "tools", "bench_ops.py"), "--rays", "1e8", "--reps", "3", "--only",
                       "woltersine,primaryLL,secondaryLL,wsPrimary,wsSecondary,wsPrimaryB,wsSecondaryB,zernsurf36,zernconic36"],
                 int(1e8), [], "Legendre-Legendre / Wolter-Schwarzschild / woltersine / Zernike kernels one by one "
