@@ -44,8 +44,8 @@ GAP, GRATLEN = 50., 95.                  # sector.py:253-254
 class Api:
     """The five namespaces the trace needs.  xp = the array module of the ray columns."""
 
-    def __init__(self, sources, surf, tran, anal, xp):
-        self.sources, self.surf, self.tran, self.anal, self.xp = sources, surf, tran, anal, xp
+    def __init__(self, sources, surf, tran, anal, xp, conic=None):
+        self.sources, self.surf, self.tran, self.anal, self.xp, self.conic = sources, surf, tran, anal, xp, conic
 
     @staticmethod
     def amd():
@@ -54,7 +54,8 @@ class Api:
         import pyxfocus_amd.sources as sources
         import pyxfocus_amd.surfaces as surf
         import pyxfocus_amd.transformations as tran
-        return Api(sources, surf, tran, anal, torch)
+        from pyxfocus_amd import conicsolve
+        return Api(sources, surf, tran, anal, torch, conicsolve)
 
     def zeros(self, n, like):
         if self.xp is np:

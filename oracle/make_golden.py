@@ -24,6 +24,8 @@ and the outputs the reference produced for them.  No reference source text is st
                      functions OUTSIDE this set; those imports are satisfied by EMPTY module
                      objects whose attributes raise when touched, so nothing but the reference's
                      own NumPy code can have produced a recorded number.
+  alignment.npz      examples/single_pass_alignment.py (examples/axro/singlePassAlignment.py:20-190) through the
+                     reference's own modules: Zernike wavefront (OPD), misaligned primary / pair, applyT, centroids.
   config5.npz        a small Arcus-style multi-shell trace (sector.py:540-757 call shape) through
                      the reference's own surfaces.py / transformations.py / analyses.py wrappers
                      over the compiled Fortran: per-shell SPO pair, grating stage, focusY.
@@ -251,16 +253,54 @@ def gold_config5(tran, src, anal, surf):
         len(r[1]), out["grating_rows"], out["dz"], *blob["centroid_w"]))
 
 
+ALIGN_GOLD = {"seed": 0, "nterms": 21, "rad": 125., "num": 3000, "masknum": 15,
+              "primalign": [0, 0, 0, 1e-5, -2e-5, 0.], "detalign": [.1, 0, .5, 0, 1e-4, 0.], "secalign": [0, 0, .02, 0, 1e-5, 0.]}
+
+
+def gold_alignment(tran, src, anal, surf):
+    """examples/single_pass_alignment.py (the reference's examples/axro/singlePassAlignment.py:20-190) on the
+    reference's OWN modules: Hartmann-mask wavefront off a Zernike surface (OPD variants), through a misaligned
+    primary / mirror pair with coords bookkeeping and applyT(inverse), slit centroids by boolean weights."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import single_pass_alignment as S
+    a = S.Api(src, surf, tran, anal, np, sys.modules["PyXFocus.conicsolve"])
+    g = ALIGN_GOLD
+    np.random.seed(g["seed"])
+    ro, ao = cases.noll_orders(g["nterms"])
+    coeff = np.random.normal(0, 1e-4, g["nterms"])
+    rays, mask = S.createWavefront(a, g["rad"], g["num"], coeff, ro, ao, masknum=g["masknum"])
+    blob = {"par/" + k: np.array(v) for k, v in g.items()}
+    blob["coeff"], blob["rorder"], blob["aorder"] = coeff, ro, ao
+    for k, v in zip(cases.ALLCOLS, rays):
+        blob["wavefront/" + k] = v.copy()
+    blob["mask"] = mask
+    cen, r = S.traceThroughPrimary(a, [x.copy() for x in rays], mask, g["masknum"], primalign=np.array(g["primalign"]),
+                                   detalign=np.array(g["detalign"]))
+    blob["primary/cen"] = cen
+    for k, v in zip(cases.ALLCOLS, r):
+        blob["primary/" + k] = v
+    cen, r = S.traceThroughPair(a, [x.copy() for x in rays], mask, g["masknum"], primalign=np.array(g["primalign"]),
+                                secalign=np.array(g["secalign"]))
+    blob["pair/cen"] = cen
+    for k, v in zip(cases.ALLCOLS, r):
+        blob["pair/" + k] = v
+    np.savez_compressed(os.path.join(OUT, "alignment.npz"), **blob)
+    print("alignment: %d rays, first slit centroid primary (%.6f, %.6f), pair (%.6f, %.6f)" % (
+        len(rays[1]), blob["primary/cen"][0, 0], blob["primary/cen"][1, 0], cen[0, 0], cen[1, 0]))
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5")
+    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5, alignment")
     only = [t for t in ap.parse_args().only.split(",") if t]
     os.makedirs(OUT, exist_ok=True)
     ref = api.load_ref()
     tran, src = shim_reference_python(ref)
-    if not only or "analyses" in only or "config5" in only:
+    if not only or "analyses" in only or "config5" in only or "alignment" in only:
         anal, surf = shim_reference_analyses(ref)
+        if not only or "alignment" in only:
+            gold_alignment(tran, src, anal, surf)
         if not only or "analyses" in only:
             gold_analyses(ref, tran, anal, surf)
         if not only or "config5" in only:

@@ -127,8 +127,16 @@ def bind(be):
     def copy_rays(rays):
         return [np.copy(r) for r in rays]
 
+    def applyT(rays, coords, inverse=False):                       # transformations.py:257-280
+        i = 2 if inverse is True else 0
+        on = np.ones(np.shape(rays)[1])
+        pos = np.dot(coords[i + 1], [rays[1], rays[2], rays[3], on])[:3]
+        wave = np.dot(coords[i], [rays[4], rays[5], rays[6], on])[:3]
+        norm = np.dot(coords[i], [rays[7], rays[8], rays[9], on])[:3]
+        return [rays[0], pos[0], pos[1], pos[2], wave[0], wave[1], wave[2], norm[0], norm[1], norm[2]]
+
     for f in (rotationM, translationM, newCoords, transform, itransform, steerX, steerY, reflect, radgrat, vignette,
-              applyTPos, copy_rays):
+              applyTPos, copy_rays, applyT):
         setattr(tran, f.__name__, f)
 
     # ---- analyses.py --------------------------------------------------------------------------
@@ -325,3 +333,40 @@ def bind(be):
     for f in (annulus, subannulus, circularbeam, pointsource):
         setattr(sources, f.__name__, f)
     return sources, surf, tran, anal
+
+
+def conic_namespace():
+    """conicsolve.primrad / secrad / woltparam / primfocus (conicsolve.py:7-15, 29-37, 51-64), NumPy as there."""
+    ns = types.SimpleNamespace()
+
+    def _pde(r0, z0, psi):
+        alpha = .25 * np.arctan(r0 / z0)
+        thetah = 2 * (1 + 2 * psi) / (1 + psi) * alpha
+        thetap = 2 * psi / (1 + psi) * alpha
+        p = z0 * np.tan(4 * alpha) * np.tan(thetap)
+        d = z0 * np.tan(4 * alpha) * np.tan(4 * alpha - thetah)
+        e = np.cos(4 * alpha) * (1 + np.tan(4 * alpha) * np.tan(thetah))
+        return p, d, e
+
+    def primrad(z, r0, z0, psi=1.):
+        p, d, e = _pde(r0, z0, psi)
+        return np.sqrt(p ** 2 + 2 * p * z + (4 * e ** 2 * p * d) / (e ** 2 - 1))
+
+    def secrad(z, r0, z0, psi=1.):
+        p, d, e = _pde(r0, z0, psi)
+        return np.sqrt(e ** 2 * (d + z) ** 2 - z ** 2)
+
+    def woltparam(r0, z0):
+        alpha = .25 * np.arctan(r0 / z0)
+        thetah, thetap = 3 * alpha, alpha
+        p = z0 * np.tan(4 * alpha) * np.tan(thetap)
+        d = z0 * np.tan(4 * alpha) * np.tan(4 * alpha - thetah)
+        e = np.cos(4 * alpha) * (1 + np.tan(4 * alpha) * np.tan(thetah))
+        return alpha, p, d, e
+
+    def primfocus(r0, z0):
+        alpha, p, d, e = woltparam(r0, z0)
+        return z0 + 2 * e ** 2 * d / (e ** 2 - 1)
+
+    ns.primrad, ns.secrad, ns.woltparam, ns.primfocus = primrad, secrad, woltparam, primfocus
+    return ns

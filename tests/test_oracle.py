@@ -239,3 +239,34 @@ def test_reference_conditioning_one_ulp(port):
     assert flip.sum() <= 30 and (d[flip] < 1e-4).all(), (flip.sum(), d.max())            # measured 10 per 4e6 rays
     # ... while the spot itself does not care: rmsCentroid moves by ~1e-13 mm
     assert abs(cases.rms_centroid(a["x"], a["y"]) - cases.rms_centroid(b["x"], b["y"])) < 1e-10
+
+
+def test_wrappers_alignment_equals_reference_python(port, golden):
+    """examples/single_pass_alignment.py on oracle/wrappers.py == the same driver on the reference's own
+    modules (tests/golden/alignment.npz): Zernike wavefront with OPD, misaligned primary / pair, coords
+    bookkeeping + applyT(inverse), slit centroids with boolean weights -- bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import single_pass_alignment as S
+    from oracle import wrappers
+    g = golden["alignment"]
+    a = S.Api(*wrappers.bind(port), np, wrappers.conic_namespace())
+    np.random.seed(int(g["par/seed"]))
+    coeff = np.random.normal(0, 1e-4, int(g["par/nterms"]))
+    assert np.array_equal(coeff, g["coeff"])
+    mn = int(g["par/masknum"])
+    rays, mask = S.createWavefront(a, float(g["par/rad"]), int(g["par/num"]), coeff, g["rorder"], g["aorder"], masknum=mn)
+    assert np.array_equal(mask, g["mask"])
+    for k, v in zip(ALLCOLS, rays):
+        assert bits_equal(v, g["wavefront/" + k]).all(), k
+    cen, r = S.traceThroughPrimary(a, [x.copy() for x in rays], mask, mn, primalign=g["par/primalign"],
+                                   detalign=g["par/detalign"])
+    assert np.array_equal(cen, g["primary/cen"])
+    for k, v in zip(ALLCOLS, r):
+        assert bits_equal(v, g["primary/" + k]).all(), k
+    cen, r = S.traceThroughPair(a, [x.copy() for x in rays], mask, mn, primalign=g["par/primalign"],
+                                secalign=g["par/secalign"])
+    assert np.array_equal(cen, g["pair/cen"])
+    for k, v in zip(ALLCOLS, r):
+        assert bits_equal(v, g["pair/" + k]).all(), k
