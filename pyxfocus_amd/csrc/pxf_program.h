@@ -11,7 +11,8 @@ constexpr int kMaxOps = PXF_PROGRAM_MAX_OPS;
 
 struct ProgOp {
     int code;
-    int flags;  // transform: vector groups to move
+    int flags;  // bits 0-2: transform: vector groups to move; bits 3..: ONE-HOT image of `code` (1 << (2 + code)),
+                // filled by the planner for the interpreter that tests one bit per case (pxf_program_fast.hip)
     const uint8_t *mask;
     const double *aux;
     double p[9];
@@ -23,6 +24,10 @@ struct Program {
     ProgOp op[kMaxOps];
 };
 static_assert(sizeof(Program) + sizeof(Cols) + 64 <= 4096, "program must fit the kernel-argument segment");
+
+// One-hot image of an op code (codes 1..28) above the three transform-group bits of ProgOp::flags.
+__host__ __device__ constexpr int prog_onehot(int code) { return 1 << (2 + code); }
+static_assert(PXF_OP_INDANGLE + 2 < 31, "op codes must fit the one-hot field of ProgOp::flags");
 
 template <class OP, int V>
 __device__ __forceinline__ void run_op(const OP &o, Ray (&r)[V], const bool (&sel)[V])
@@ -50,10 +55,10 @@ __device__ __forceinline__ void exec_op(int code, int flags, const double *__res
             break;
         case PXF_OP_WOLTERSECONDARY: run_op(WolterSecondaryOp{P[0], P[1], P[2]}, r, sel); break;
         case PXF_OP_TRANSFORM:
-            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
             break;
         case PXF_OP_ITRANSFORM:
-            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
             break;
         case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
         case PXF_OP_RADGRAT: run_op(RadgratOp<false>{P[0], P[1], P[2], P[3], P[4]}, r, sel); break;

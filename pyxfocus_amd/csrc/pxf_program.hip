@@ -344,6 +344,7 @@ int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, i
             pg.op[k++] = pg.op[i];
         }
     pg.nops = k;
+    for (int i = 0; i < k; i++) pg.op[i].flags |= prog_onehot(pg.op[i].code);
     if (zern_op) *zern_op = zk;
     if (zk >= 0 && k > PXF_PROGRAM_MAX_OPS_ZERN) return PXF_ERANGE;
     pg.load = load;

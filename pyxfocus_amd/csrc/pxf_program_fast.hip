@@ -252,31 +252,60 @@ __device__ __forceinline__ void fast_spocone(const double *__restrict__ P, Ray (
     }
 }
 
+// One operation on the V rays of a thread, two dispatch forms (A/B'd on one box, tools/ab_programs.py):
+//
+// FLAT (ordinary programs): a sequence of independent `if`s, each testing ONE BIT of a one-hot image of the
+// op code that the planner stores in the program (opaque to the compiler).  A `switch (code)` -- or ifs on
+// `code`, which the compiler turns back into one -- is lowered to a decision tree whose every level ends in a
+// block of phi copies of the whole ray state (18+ v_mov_b64 per level, several levels per op): with nine
+// cases the flat form is 3-17 % faster (config 2: 2.16 -> 2.10 ms, config 3: 2.63 -> 2.19 ms per 1e8 rays).
+// SWITCH (segmented programs, and the 25-case exact interpreter of pxf_program.h): there the flat form
+// LOSES (SPO pair 2.9 -> 3.4 ms; exact programs 5-50 % slower: two dozen taken branches per op, and
+// per-lane parameters read from LDS ahead of every untaken case).
 template <int V, bool NT>
-__device__ __forceinline__ void exec_fast(int code, int flags, const double *__restrict__ P, const double *aux,
-                                          int64_t vv, Ray (&r)[V])
+__device__ __forceinline__ void exec_fast_indangle(const double *__restrict__ P, const double *aux, int64_t vv,
+                                                   Ray (&r)[V])
+{
+    bool sel[V];  // diagnostic output column: the library's own IndAngleOp (ocml acos)
+    unsigned wm[V];
+    double t[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) sel[k] = true;
+    IndAngleOp{(int)P[0]}.template apply<V>(r, sel, wm);
+#pragma unroll
+    for (int k = 0; k < V; k++) t[k] = r[k].c[AUX];
+    store_col<V, NT>(const_cast<double *>(aux), vv, t, sel);
+}
+
+template <int V, bool NT>
+__device__ __forceinline__ void exec_fast_flat(int flags, const double *__restrict__ P, const double *aux, int64_t vv,
+                                               Ray (&r)[V])
+{
+    if (flags & prog_onehot(PXF_OP_TRANSFORM)) fast_transform<V, false>(P, flags & 7, r);
+    if (flags & prog_onehot(PXF_OP_WOLTERPRIMARY)) fast_wolterprimary<V>(P, r);
+    if (flags & prog_onehot(PXF_OP_REFLECT)) fast_reflect<V>(r);
+    if (flags & prog_onehot(PXF_OP_WOLTERSECONDARY)) fast_woltersecondary<V>(P, r);
+    if (flags & prog_onehot(PXF_OP_FLAT)) fast_flat<V>(r);
+    if (flags & prog_onehot(PXF_OP_SPOCONE)) fast_spocone<V>(P, r);
+    if (flags & prog_onehot(PXF_OP_RADGRAT)) fast_radgrat<V>(P, r);
+    if (flags & prog_onehot(PXF_OP_ITRANSFORM)) fast_transform<V, true>(P, flags & 7, r);
+    if (flags & prog_onehot(PXF_OP_INDANGLE)) exec_fast_indangle<V, NT>(P, aux, vv, r);
+}
+
+template <int V, bool NT>
+__device__ __forceinline__ void exec_fast_switch(int code, int flags, const double *__restrict__ P, const double *aux,
+                                                 int64_t vv, Ray (&r)[V])
 {
     switch (code) {
-        case PXF_OP_INDANGLE: {  // diagnostic output column: the library's own IndAngleOp (ocml acos)
-            bool sel[V];
-            unsigned wm[V];
-            double t[V];
-#pragma unroll
-            for (int k = 0; k < V; k++) sel[k] = true;
-            IndAngleOp{(int)P[0]}.template apply<V>(r, sel, wm);
-#pragma unroll
-            for (int k = 0; k < V; k++) t[k] = r[k].c[AUX];
-            store_col<V, NT>(const_cast<double *>(aux), vv, t, sel);
-            break;
-        }
         case PXF_OP_FLAT: fast_flat<V>(r); break;
         case PXF_OP_WOLTERPRIMARY: fast_wolterprimary<V>(P, r); break;
         case PXF_OP_WOLTERSECONDARY: fast_woltersecondary<V>(P, r); break;
-        case PXF_OP_TRANSFORM: fast_transform<V, false>(P, flags, r); break;
-        case PXF_OP_ITRANSFORM: fast_transform<V, true>(P, flags, r); break;
+        case PXF_OP_TRANSFORM: fast_transform<V, false>(P, flags & 7, r); break;
+        case PXF_OP_ITRANSFORM: fast_transform<V, true>(P, flags & 7, r); break;
         case PXF_OP_REFLECT: fast_reflect<V>(r); break;
         case PXF_OP_RADGRAT: fast_radgrat<V>(P, r); break;
         case PXF_OP_SPOCONE: fast_spocone<V>(P, r); break;
+        case PXF_OP_INDANGLE: exec_fast_indangle<V, NT>(P, aux, vv, r); break;
         default: break;
     }
 }
@@ -319,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void program_fast_kernel(Cols c, int64_t fi
             }
         }
         for (int i = 0; i < pg.nops; i++)
-            exec_fast<V, NT>(pg.op[i].code, pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r);
+            exec_fast_flat<V, NT>(pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r);
 #pragma unroll
         for (int col = 0; col < 10; col++) {
             if (pg.store & B(col)) {
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void program_fast_seg_kernel(Cols c, int64_
                 }
             }
             for (int i = 0; i < pg.nops; i++)
-                exec_fast<V, NT>(pg.op[i].code, pg.op[i].flags, &s_par[sb][i][0], pg.op[i].aux, vv, r);
+                exec_fast_switch<V, NT>(pg.op[i].code, pg.op[i].flags, &s_par[sb][i][0], pg.op[i].aux, vv, r);
 #pragma unroll
             for (int col = 0; col < 10; col++) {
                 if (pg.store & B(col)) {

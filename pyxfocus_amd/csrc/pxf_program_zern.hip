@@ -46,10 +46,10 @@ __device__ __forceinline__ void exec_op_lite(int code, int flags, const double *
         case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
         case PXF_OP_FLATOPD: run_op(FlatOp<true>{P[0]}, r, sel); break;
         case PXF_OP_TRANSFORM:
-            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
             break;
         case PXF_OP_ITRANSFORM:
-            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags}, r, sel);
+            run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
             break;
         case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
         default: break;
