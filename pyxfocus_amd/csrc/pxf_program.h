@@ -39,11 +39,45 @@ __device__ __forceinline__ void run_op(const OP &o, Ray (&r)[V], const bool (&se
 // One operation on the V rays of a thread.  `P` points at the op's nine doubles: the kernel
 // arguments for an ordinary program (wave-uniform -> scalar loads), or the workgroup's LDS copy of
 // the ray's SEGMENT parameters for a segmented program.
-template <int V, bool NT>
+// The operations of the common chains (the BASELINE configs: frame changes, Wolter-I pair, reflect, flat, radial
+// grating, SPO cone, indAngle).  A program made only of these runs in a kernel instantiation whose switch has
+// 9 cases instead of 25: the compiler lowers a switch to a compare tree with a block of whole-ray-state phi
+// copies per level, so fewer cases = fewer levels = fewer copies.
+constexpr int kHotOps = prog_onehot(PXF_OP_TRANSFORM) | prog_onehot(PXF_OP_ITRANSFORM) | prog_onehot(PXF_OP_WOLTERPRIMARY) |
+                        prog_onehot(PXF_OP_WOLTERSECONDARY) | prog_onehot(PXF_OP_REFLECT) | prog_onehot(PXF_OP_FLAT) |
+                        prog_onehot(PXF_OP_RADGRAT) | prog_onehot(PXF_OP_SPOCONE) | prog_onehot(PXF_OP_INDANGLE);
+
+template <int V, bool NT, bool HOT = false>
 __device__ __forceinline__ void exec_op(int code, int flags, const double *__restrict__ P,
                                         const double *__restrict__ aux, int64_t vv, Ray (&r)[V],
                                         const bool (&sel)[V])
 {
+    if constexpr (HOT) {
+        switch (code) {
+            case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
+            case PXF_OP_WOLTERPRIMARY: run_op(WolterPrimaryOp<false>{P[0], P[1], P[2], 0.}, r, sel); break;
+            case PXF_OP_WOLTERSECONDARY: run_op(WolterSecondaryOp{P[0], P[1], P[2]}, r, sel); break;
+            case PXF_OP_TRANSFORM:
+                run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
+                break;
+            case PXF_OP_ITRANSFORM:
+                run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
+                break;
+            case PXF_OP_REFLECT: run_op(ReflectOp{}, r, sel); break;
+            case PXF_OP_RADGRAT: run_op(RadgratOp<false>{P[0], P[1], P[2], P[3], P[4]}, r, sel); break;
+            case PXF_OP_SPOCONE: run_op(SpoConeOp{P[0], P[1], P[2], P[3]}, r, sel); break;
+            case PXF_OP_INDANGLE: {
+                run_op(IndAngleOp{(int)P[0]}, r, sel);
+                double t[V];
+#pragma unroll
+                for (int k = 0; k < V; k++) t[k] = r[k].c[AUX];
+                store_col<V, NT>(const_cast<double *>(aux), vv, t, sel);
+                break;
+            }
+            default: break;
+        }
+        return;
+    }
     switch (code) {
         case PXF_OP_FLAT: run_op(FlatOp<false>{0.}, r, sel); break;
         case PXF_OP_FLATOPD: run_op(FlatOp<true>{P[0]}, r, sel); break;

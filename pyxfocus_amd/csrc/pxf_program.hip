@@ -18,7 +18,8 @@
 namespace pxf {
 
 // ANYMASK=false instantiations carry no per-op mask code (no saved copy of the ray -> fewer VGPRs)
-template <int V, bool NT, bool ANYMASK>
+// HOT: every operation of the program is one of kHotOps (unmasked programs only): the 9-case interpreter step
+template <int V, bool NT, bool ANYMASK, bool HOT = false>
 __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, 
 #pragma unroll
                 for (int k = 0; k < V; k++) sel[k] = true;
             }
-            exec_op<V, NT>(o.code, o.flags, o.p, o.aux, vv, r, sel);
+            exec_op<V, NT, HOT>(o.code, o.flags, o.p, o.aux, vv, r, sel);
             if (masked) {  // unselected rays keep every register
 #pragma unroll
                 for (int k = 0; k < V; k++)
@@ -87,7 +88,7 @@ struct SegInfo {
     int nseg;
 };
 
-template <bool NT, bool ANYMASK>
+template <bool NT, bool ANYMASK, bool HOT = false>
 __global__ __launch_bounds__(kBlock) void program_seg_kernel(Cols c, int64_t nvec, Program pg, SegInfo sg)
 {
     constexpr int V = 2;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void program_seg_kernel(Cols c, int64_t nve
 #pragma unroll
                     for (int k = 0; k < V; k++) sel[k] = true;
                 }
-                exec_op<V, NT>(o.code, o.flags, &s_par[sb][i][0], o.aux, vv, r, sel);
+                exec_op<V, NT, HOT>(o.code, o.flags, &s_par[sb][i][0], o.aux, vv, r, sel);
                 if (masked) {
 #pragma unroll
                     for (int k = 0; k < V; k++)
@@ -409,8 +410,15 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
         force_v = e ? atoi(e) : 0;
     }
     const int64_t nvec2 = (aligned && force_v != 1) ? num / 2 : 0;
-#define PXF_PLAUNCH(V, T, A, FIRST, NVEC)                                                                   \
-    hipLaunchKernelGGL((program_kernel<V, T, A>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg)
+    bool hot = !anymask;
+    for (int i = 0; i < pg.nops; i++) hot &= (pg.op[i].flags & kHotOps) != 0;
+#define PXF_PLAUNCH(V, T, A, FIRST, NVEC)                                                                             \
+    do {                                                                                                              \
+        if (hot && !(A))                                                                                              \
+            hipLaunchKernelGGL((program_kernel<V, T, false, true>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((program_kernel<V, T, A>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg);  \
+    } while (0)
 #define PXF_PLAUNCH_V(V, FIRST, NVEC)                      \
     do {                                                   \
         if (anymask) {                                     \
@@ -479,8 +487,15 @@ int pxf_program_run_segments(const pxf_op_t *ops, int32_t nops, const double *se
         if (nt) hipLaunchKernelGGL((program_seg_kernel<true, true>), grid, block, 0, s, c, nvec, pg, sg);
         else hipLaunchKernelGGL((program_seg_kernel<false, true>), grid, block, 0, s, c, nvec, pg, sg);
     } else {
-        if (nt) hipLaunchKernelGGL((program_seg_kernel<true, false>), grid, block, 0, s, c, nvec, pg, sg);
-        else hipLaunchKernelGGL((program_seg_kernel<false, false>), grid, block, 0, s, c, nvec, pg, sg);
+        bool hot = true;
+        for (int i = 0; i < pg.nops; i++) hot &= (pg.op[i].flags & kHotOps) != 0;
+        if (hot) {
+            if (nt) hipLaunchKernelGGL((program_seg_kernel<true, false, true>), grid, block, 0, s, c, nvec, pg, sg);
+            else hipLaunchKernelGGL((program_seg_kernel<false, false, true>), grid, block, 0, s, c, nvec, pg, sg);
+        } else {
+            if (nt) hipLaunchKernelGGL((program_seg_kernel<true, false>), grid, block, 0, s, c, nvec, pg, sg);
+            else hipLaunchKernelGGL((program_seg_kernel<false, false>), grid, block, 0, s, c, nvec, pg, sg);
+        }
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
