@@ -437,7 +437,7 @@ def bench_config5(n, steps, dev, rank, world, dist, pxf, anal, tran, surf, grata
         tot = sum(best)
         out["spo_stage_" + tag] = {"ms": tot, "source_ms": best[0], "spo_pair_program_ms": best[1], "move_flat_ms": best[2],
                                    "launches": 3, "rays_per_s": n / (tot * 1e-3),
-                                   "program_GBps": (48 + 72 + 16) * n / (best[1] * 1e-3) / 1e9}   # 6 in, 9 out, 2 angle columns
+                                   "program_GBps": (72 + 72 + 16) * n / (best[1] * 1e-3) / 1e9}   # 9 in (a cone miss keeps position and normal), 9 out, 2 angle columns
         del prog
         res = res[:5]                      # (drop the compiled program: it keeps the two graze-angle columns alive)
         torch.cuda.empty_cache()

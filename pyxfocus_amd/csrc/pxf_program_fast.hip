@@ -3,7 +3,7 @@
 // The default program kernel (pxf_program.hip) is bit-identical to the reference and, for the
 // two-bounce chain, no longer HBM-bound: 1237 VALU wave-instructions per wave (two rays per lane),
 // most of them IEEE fp64 divides / square roots and the 3-vector work of the Newton loops, hold it at
-// 2.6 ms per 1e8 rays where 120 B/ray allow ~1.95 ms (profiles/r02b_config2_kernels.md).  The
+// 2.6 ms per 1e8 rays where 120 B/ray allow ~1.95 ms (profiles/r02c_config2_kernels.md).  The
 // north-star asks for < 1e-10 mm RMS, not bit identity.  This kernel trades the bits for the roof:
 //
 //  * Wolter-I primary / secondary (woltsurf.f95:7-54, 114-161).  The surfaces are quadrics, so along a

@@ -183,7 +183,7 @@ def write_tables(tag, target, ks, rays, note, launch_bytes):
         if op.split("<")[0] in ("program_kernel", "program_zern_kernel", "program_fast_kernel") and target not in ("ops", "config5"):
             alg.setdefault(op, 120)                 # the configs' programs: 6 columns in, 9 out
         if op.split("<")[0] in ("program_seg_kernel", "program_fast_seg_kernel"):
-            alg.setdefault(op, 136)                 # SPO pair: 6 in, 9 out, two graze-angle columns
+            alg.setdefault(op, 160)                 # SPO pair: 9 in (a cone miss keeps position+normal), 9 out, 2 angle columns
     lines = ["# rocprofv3 summary `%s` / `%s`" % (tag, target), "", note, "",
              "Durations: `rocprofv3 --kernel-trace --stats`; HBM bytes: two `--pmc` passes (FETCH_SIZE x 1024 x 2 per "
              "MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE x 1024); instruction mix: `--pmc` SQ passes. "
