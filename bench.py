@@ -710,15 +710,34 @@ def main():
 
     want = args.configs if args.configs is not None else ("3,4,5" if n_gpus == 1 else "5")
     want = [t for t in want.split(",") if t]
-    c5 = None
+    c5, c5_trouble = None, False
     if "5" in want:                  # every rank: the focal-plane exchange of config 5 is a collective
-        try:
-            c5 = bench_config5(int(args.config_rays), args.config_steps, dev, rank, world, dist, pxf, anal, tran, surf)
-        except Exception as e:
-            c5 = {"error": repr(e)[:300]}
-            if dist:
-                raise
-        torch.cuda.empty_cache()
+        if dist:
+            # Multi-rank: the headline line must survive whatever this optional part does.  It runs in a worker
+            # thread under a watchdog: a rank that fails or hangs in a collective (its peers then hang too) gives up
+            # after the deadline on EVERY rank, rank 0 still prints its line, and all ranks leave without
+            # another collective (os._exit below).
+            import threading
+            box = {}
+
+            def work():
+                try:
+                    torch.cuda.set_device(local)
+                    box["r"] = bench_config5(int(args.config_rays), args.config_steps, dev, rank, world, dist, pxf, anal,
+                                             tran, surf)
+                except Exception as e:
+                    box["r"] = {"error": repr(e)[:300]}
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("PXF_BENCH_CONFIG5_TIMEOUT", "420")))
+            c5 = box.get("r") or {"error": "config 5 did not finish within its watchdog deadline (a collective hung?)"}
+            c5_trouble = "error" in c5
+        else:
+            try:
+                c5 = bench_config5(int(args.config_rays), args.config_steps, dev, rank, world, dist, pxf, anal, tran, surf)
+            except Exception as e:
+                c5 = {"error": repr(e)[:300]}
+            torch.cuda.empty_cache()
 
     out = None
     if rank == 0:
@@ -772,6 +791,9 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist:
+        if c5_trouble:               # ranks may be out of step: no further collective, leave now (line already printed)
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 
