@@ -58,11 +58,35 @@ def main():
     assert rec.launches == 1
     for k, v in to_host(t).items():
         assert bits_equal(v, want[k]).all(), k
+    # the tolerance-mode program, NT instantiation: < 1e-10 mm RMS vs the oracle (config-2 chain)
+    t = to_dev(c)
+    with pxf.fused(fast=True) as rec:
+        cases.chain_config2(native, t)
+    assert rec.fast_launches == 1
+    got = to_host(t)
+    d2 = sum((got[k] - want[k]) ** 2 for k in "xyz")
+    assert np.sqrt(d2[d2 < 1e-14].mean()) < 1e-10 and (d2 >= 1e-14).sum() <= 1, np.sqrt(d2.mean())
+    # segmented programs (exact and tolerance mode), NT instantiations: the Arcus SPO stage vs the shell loop
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "examples"))
+    import arcus_sector as A
+    kw = dict(rows=(0, 5), modules_per_row=1, shell_stride=9)
+    np.random.seed(8)
+    a = A.defineSPOaperture(A.Api.amd(), 180, **kw)
+    for fast in (False, True):
+        np.random.seed(8)
+        b = A.defineSPOaperture_segmented(180, source="numpy", fast=fast, **kw)
+        for k, u, v in zip(ALLCOLS, a[0], b[0]):
+            u, v = u.cpu().numpy(), v.cpu().numpy()
+            if fast:
+                assert np.abs(u - v).max() <= 1e-9 * (1 + np.abs(u).max()), k
+            else:
+                assert bits_equal(u, v).all(), k
     for nmax in range(1, 16):
         zernike_order_check(port, nmax)
         zernike_order_check(port, nmax, masked=True)
     torch.cuda.synchronize()
-    print("nt sweep ok: %d cases x (plain, masked), fused chain, 15 Zernike orders x (plain, masked)" % ncase)
+    print("nt sweep ok: %d cases x (plain, masked), fused chain exact + fast, segmented SPO exact + fast, "
+          "15 Zernike orders x (plain, masked, fused)" % ncase)
 
 
 if __name__ == "__main__":
