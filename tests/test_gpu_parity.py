@@ -248,6 +248,84 @@ def test_full_size_1e9_rays_properties(port):
             assert np.abs(u - c[k]).max() < 5e-10, (k, np.abs(u - c[k]).max())
 
 
+def test_full_size_1e9_rays_zernike_properties(port):
+    """BASELINE config 4 at its full size: 1e9 rays, the 36-term Zernike surface as ONE program
+    (zernsurf -> reflect -> flat).  Size-independent properties over all rays, a strided sample checked
+    against an independent evaluation of the surface polynomial (torch, from pxf_zernike_monomials), and the
+    first / last 1e5 global ray indices against the oracle."""
+    import ctypes as C
+    import math
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.sources as sources
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from pyxfocus_amd import _lib
+    free, total = torch.cuda.mem_get_info()
+    n = 1_000_000_000
+    if free < 100e9:
+        pytest.skip("needs ~90 GB of free HBM")
+    rng = np.random.default_rng(4)
+    coeff = rng.normal(0., 1e-3, 36)
+    coeff[0] = 0.
+    ro, ao = cases.noll_orders(36)
+    ro, ao = np.ascontiguousarray(ro, np.int32), np.ascontiguousarray(ao, np.int32)
+
+    def prep(rays):
+        rays[3].fill_(10.)
+        rays[4].fill_(.01)
+        rays[6].fill_(-math.sqrt(1 - 1e-4))
+
+    rays = sources.circularbeam(50., n, rng="philox", seed=41)
+    prep(rays)
+    surf.zernsurf(rays, coeff, 50., rorder=ro, aorder=ao)
+    # (1) every ray sits on the surface z = S(x, y): independent Horner evaluation on a strided 1e6-ray sample
+    mono = np.zeros(36)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    assert _lib.lib().pxf_zernike_monomials(coeff.ctypes.data_as(dp), ro.ctypes.data_as(ip), ao.ctypes.data_as(ip), 36, 7,
+                                            mono.ctypes.data_as(dp)) == 0
+    xs, ys, zs = [rays[j][::1000] for j in (1, 2, 3)]
+    u, v = xs / 50., ys / 50.
+    sv = torch.zeros_like(u)
+    N = 7
+    for j in range(N, -1, -1):
+        off = j * (N + 1) - j * (j - 1) // 2
+        p = torch.full_like(u, float(mono[off]))
+        for i in range(1, N - j + 1):
+            p = p * u + float(mono[off + i])
+        sv = sv * v + p
+    assert float((zs - sv).abs().max()) < 1e-12
+    nrm = rays[7] * rays[7] + rays[8] * rays[8] + rays[9] * rays[9]
+    assert float((nrm - 1).abs().max()) < 1e-12 and bool(torch.isfinite(rays[1]).all())
+    del nrm, sv, p, u, v
+    head = [r[:100_000].cpu().numpy() for r in rays]
+    tail = [r[-100_000:].cpu().numpy() for r in rays]
+    # (2) the whole config-4 chain as one program == zernsurf (above) + reflect + flat, launch by launch
+    tran.reflect(rays)
+    surf.flat(rays)
+    keep_x, keep_l = rays[1].clone(), rays[4].clone()
+    del rays
+    torch.cuda.empty_cache()
+    rays = sources.circularbeam(50., n, rng="philox", seed=41)
+    prep(rays)
+    with pxf.fused() as rec:
+        surf.zernsurf(rays, coeff, 50., rorder=ro, aorder=ao)
+        tran.reflect(rays)
+        surf.flat(rays)
+    assert rec.launches == 1
+    assert float((rays[1] - keep_x).abs().max()) < 1e-12 and float((rays[4] - keep_l).abs().max()) < 1e-14
+    assert bool((rays[3] == 0).all())
+    del rays, keep_x, keep_l
+    torch.cuda.empty_cache()
+    # (3) first / last 1e5 global indices through the oracle
+    for first, got in ((0, head), (n - 100_000, tail)):
+        small = sources.circularbeam(50., 100_000, rng="philox", seed=41, first_index=first)
+        prep(small)
+        c = {k: t.cpu().numpy() for k, t in zip(ALLCOLS, small)}
+        port.zernsurf.tracezern(*[c[k] for k in ALLCOLS[1:]], coeff, ro, ao, 50.)
+        for k, u_ in zip(ALLCOLS, got):
+            assert np.abs(u_ - c[k]).max() <= 2e-11 + 1e-12 * np.abs(c[k]).max(), (k, np.abs(u_ - c[k]).max())
+
+
 def test_streams_and_graph_capture(port):
     """Every launch goes to torch's CURRENT stream (no implicit sync, nothing allocated by the
     library), so a trace can run on a side stream and be captured into a HIP graph and replayed."""
