@@ -511,6 +511,28 @@ def bench_config5(n, steps, dev, rank, world, dist, pxf, anal, tran, surf, grata
         out["gratArray_while_loop"] = {"rays": int(r2[1].shape[0]), "grating_rows": nrows, "focusY_dz_mm": dz2,
                                        "ms": (t2 - t1) * 1e3, "rays_per_s": r2[1].shape[0] / (t2 - t1),
                                        "spo_stage_ms_incl_compile": (t1 - t0) * 1e3}
+        # (e) the same stage with every ray walking the fan in registers (grating.fanArray: two launches,
+        #     bit-identical to the loop -- tests/test_gpu_config5.py), same bundle size and at the full share
+        from pyxfocus_amd import grating
+        keep = [c.clone() for c in r2[1:3]]
+        for tag, nn in (("same_rays", nper), ("full_share", per)):
+            del r2, w2
+            torch.cuda.empty_cache()
+            r2, w2, minfoc, lmax, coords, _ = A.defineSPOaperture_segmented(nn, source="philox", seed=300 + rank)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dz3, nrows3 = A.gratArray(api, r2, A.OUTERRAD, hubdist, angle, A.INC, weights=w2, order=-3, blazeYaw=A.YAW,
+                                      wave=2.4, coords=coords, focus_kw={"group": grp} if dist else None,
+                                      fan=grating.fanArray)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            ent = {"rays": int(r2[1].shape[0]), "grating_rows": nrows3, "focusY_dz_mm": dz3, "ms": (t2 - t1) * 1e3,
+                   "rays_per_s": r2[1].shape[0] / (t2 - t1)}
+            if tag == "same_rays":
+                ent["bit_identical_to_while_loop"] = bool(all(torch.equal(torch.nan_to_num(u), torch.nan_to_num(v))
+                                                              for u, v in zip(keep, r2[1:3])) and dz3 == dz2)
+            out["gratArray_fan_" + tag] = ent
+        del keep
     except Exception as e:
         out["gratArray_while_loop"] = {"error": repr(e)[:300]}
     return out

@@ -57,6 +57,15 @@ class Api:
         from pyxfocus_amd import conicsolve
         return Api(sources, surf, tran, anal, torch, conicsolve)
 
+    def fused(self):
+        """`with api.fused():` -- on pyxfocus_amd consecutive calls run as one launch (bit-identical);
+        on any other binding (the reference's modules) a no-op."""
+        import contextlib
+        if self.xp is np:
+            return contextlib.nullcontext()
+        import pyxfocus_amd
+        return pyxfocus_amd.fused()
+
     def zeros(self, n, like):
         if self.xp is np:
             return np.zeros(n)
@@ -215,24 +224,30 @@ def defineSPOaperture_segmented(N, gap=GAP, rows=range(8), modules_per_row=None,
 
 
 def gratArray(api, rays, outerrad, hubdist, angle, inc, l=GRATLEN, weights=None, order=0, blazeYaw=0., wave=1.,
-              offX=0., coords=None, maxiter=10000, focus_kw=None):
+              offX=0., coords=None, maxiter=10000, focus_kw=None, fan=None):
     """Rays leaving the petal -> fanned grating array rotated about the hub -> back to the frame of
     the outermost grating -> best line focus (sector.py:636-757).  Returns (focusY shift, number of
-    grating rows visited)."""
+    grating rows visited).  fan: a callable with the signature of pyxfocus_amd.grating.fanArray that
+    replaces the host `while` loop over grating rows (bit-identical, two launches instead of ~226 rounds of a
+    dozen passes each); None = the reference's loop."""
     xp, tran, surf = api.xp, api.tran, api.surf
     pi = math.pi
     x, y = rays[1:3]
-    tran.transform(rays, outerrad, 0, 0, 0, 0, 0, coords=coords)
-    tran.transform(rays, 0, 0, 0, 0, 0, -pi / 2, coords=coords)
-    tran.transform(rays, 0, 0, 0, -pi / 2 - angle + inc, 0, 0, coords=coords)
-    tran.transform(rays, 0, 0, 0, 0, 0, blazeYaw, coords=coords)
-    tran.transform(rays, 0, hubdist, 0, 0, 0, 0, coords=coords)
+    with api.fused():
+        tran.transform(rays, outerrad, 0, 0, 0, 0, 0, coords=coords)
+        tran.transform(rays, 0, 0, 0, 0, 0, -pi / 2, coords=coords)
+        tran.transform(rays, 0, 0, 0, -pi / 2 - angle + inc, 0, 0, coords=coords)
+        tran.transform(rays, 0, 0, 0, 0, 0, blazeYaw, coords=coords)
+        tran.transform(rays, 0, hubdist, 0, 0, 0, 0, coords=coords)
+    ang = l * math.sin(inc - offX) / hubdist * .95
+    if fan is not None:
+        i = fan(rays, hubdist, l, ang, 160. / hubdist, order, wave, thr=.001, coords=coords, maxiter=maxiter)
+        return _gratArray_tail(api, rays, outerrad, hubdist, angle, inc, ang, i, blazeYaw, weights, coords, focus_kw)
     indg = xp.abs(xp.arcsin(rays[6])) > .001
     surf.flat(rays, ind=indg)
     rho = -xp.sqrt(x ** 2 + y ** 2) * xp.sign(y)
     ind = xp.logical_and(rho > hubdist, rho < l + hubdist)
     ind2 = ind
-    ang = l * math.sin(inc - offX) / hubdist * .95
     nrays = len(rays[1])
     i = 0
     prev = ind
@@ -253,18 +268,25 @@ def gratArray(api, rays, outerrad, hubdist, angle, inc, l=GRATLEN, weights=None,
         prev = xp.logical_or(prev, ind)
     tran.reflect(rays, ind=ind2)
     tran.radgrat(rays, 160. / hubdist, order, wave, ind=ind2)
-    tran.transform(rays, 0, 0, 0, -ang * i, 0, 0, coords=coords)
-    tran.transform(rays, 0, -hubdist, 0, 0, 0, 0, coords=coords)
-    tran.transform(rays, 0, 0, 0, 0, 0, -blazeYaw, coords=coords)
-    tran.transform(rays, 0, 0, 0, pi / 2 + angle - inc, 0, 0, coords=coords)
-    tran.transform(rays, 0, 0, 0, 0, 0, pi / 2, coords=coords)
-    tran.transform(rays, -outerrad, 0, 0, 0, 0, 0, coords=coords)
-    surf.flat(rays)
+    return _gratArray_tail(api, rays, outerrad, hubdist, angle, inc, ang, i, blazeYaw, weights, coords, focus_kw)
+
+
+def _gratArray_tail(api, rays, outerrad, hubdist, angle, inc, ang, i, blazeYaw, weights, coords, focus_kw):
+    """Undo the frames of the grating array (sector.py:718-723), flat, focusY."""
+    tran, surf, pi = api.tran, api.surf, math.pi
+    with api.fused():
+        tran.transform(rays, 0, 0, 0, -ang * i, 0, 0, coords=coords)
+        tran.transform(rays, 0, -hubdist, 0, 0, 0, 0, coords=coords)
+        tran.transform(rays, 0, 0, 0, 0, 0, -blazeYaw, coords=coords)
+        tran.transform(rays, 0, 0, 0, pi / 2 + angle - inc, 0, 0, coords=coords)
+        tran.transform(rays, 0, 0, 0, 0, 0, pi / 2, coords=coords)
+        tran.transform(rays, -outerrad, 0, 0, 0, 0, 0, coords=coords)
+        surf.flat(rays)
     return surf.focusY(rays, weights=weights, **(focus_kw or {})), i
 
 
 def traceArcus(api, N, order=-3, wave=2.4, blazeYaw=YAW, inc=INC, l=GRATLEN, gap=GAP, offX=0., offY=0.,
-               rows=range(8), modules_per_row=None, shell_stride=1, focus_kw=None):
+               rows=range(8), modules_per_row=None, shell_stride=1, focus_kw=None, fan=None):
     """The petal end to end (sector.py:253-389 with bestFocus=None, then the focal-plane tail):
     returns a dict with the focal bundle, the weights, the focusY shift, the number of grating rows
     and the weighted centroid of the diffracted line."""
@@ -277,7 +299,7 @@ def traceArcus(api, N, order=-3, wave=2.4, blazeYaw=YAW, inc=INC, l=GRATLEN, gap
     hubdist = math.sqrt(OUTERRAD ** 2 + float(foc[2]) ** 2)
     angle = math.atan(OUTERRAD / (minfoc - (lmax + gap + GRATLEN)))
     dz, nrows = gratArray(api, rays, OUTERRAD, hubdist, angle, inc, l=l, weights=weights, order=order,
-                          blazeYaw=blazeYaw, wave=wave, offX=offX, coords=coords, focus_kw=focus_kw)
+                          blazeYaw=blazeYaw, wave=wave, offX=offX, coords=coords, focus_kw=focus_kw, fan=fan)
     weights = weights * (1 - abs(offX) / inc)
     return {"rays": rays, "weights": weights, "dz": dz, "grating_rows": nrows, "hubdist": hubdist,
             "angle": angle, "coords": coords}

@@ -525,6 +525,23 @@ int pxf_source_segments(int32_t kind, double *const *cols, int64_t num, const do
                         int32_t nseg, int64_t rays_per_seg, uint64_t seed, uint64_t first_index,
                         pxf_stream_t stream);
 
+/* ---- a fanned array of radial gratings, per ray (EXTENSION: no reference function) --------------------------
+ * The `while` loop of the reference's examples/arcus/sector.py:663-704 (`gratArray`): a stack of radial gratings
+ * fanned about a common hub, walked round by round -- rotate the frame of ALL rays by one grating pitch
+ * (transform(0,0,0,ang,0,0)), flat() the rays that have not met a grating yet and are not grazing
+ * (|asin n| > thr), test  hubdist < -sqrt(x^2+y^2) sign(y) < hubdist+length, diffract the rays that passed
+ * (reflect, radgrat) at the start of the next round -- until every ray has met a grating.  The reference does
+ * this with a host loop over the whole bundle; here every ray walks the fan in registers with the same
+ * TransformOp / FlatOp / ReflectOp / RadgratOp code, bit-identical to the loop:
+ *   pxf_fan_search  rounds until each ray meets a grating: it_hit[i] = its round (-1: none within `cap`),
+ *                   *imax = the largest round (= the host loop's round count), *nmiss = rays without a hit
+ *   pxf_fan_finish  diffracts every ray at the start of round it_hit+1 and keeps rotating it up to round imax
+ * cols[1..9] = x y z l m n ux uy uz (cols[0] unused); it_hit, imax, nmiss are DEVICE buffers. */
+int pxf_fan_search(double *const *cols, int64_t num, double hubdist, double length, double ang, double thr, int32_t cap,
+                   int32_t *it_hit, int32_t *imax, uint64_t *nmiss, pxf_stream_t stream);
+int pxf_fan_finish(double *const *cols, int64_t num, double ang, double dpermm, double order, double wave,
+                   const int32_t *it_hit, int32_t imax, pxf_stream_t stream);
+
 /* ---- OPT-IN tolerance mode of the fused program ------------------------------------------------------
  * pxf_program_run / pxf_program_run_segments are bit-identical to the reference's loops
  * (surfacesf.f95 / woltsurf.f95 / transformationsf.f95) and, for Newton-heavy programs, bound by IEEE

@@ -1,0 +1,187 @@
+// pxf_fan.hip -- a fanned array of radial gratings, per ray (EXTENSION: no reference function; it is the
+// `while` loop of the reference's examples/arcus/sector.py:663-704, `gratArray`).
+//
+// The reference walks a stack of gratings fanned about a common hub with a host loop over the WHOLE bundle:
+// every round it rotates the frame of all rays by one grating pitch (`transform(0,0,0,ang,0,0)`), brings the rays
+// that have not met a grating yet to the new grating plane (`flat(ind=...)`), tests which of them land inside
+// the grating's radial extent, and diffracts those at the start of the next round (`reflect(ind)`,
+// `radgrat(ind)`) -- ~226 rounds for the Arcus petal, each a dozen passes over HBM plus a host sync
+// (2.4 s per 1e8 rays through the drop-in API).
+//
+// Here each ray walks the fan by itself, in registers, with the SAME device code the API calls run
+// (TransformOp, FlatOp, ReflectOp, RadgratOp::apply) in the same order, so the result is bit-identical to
+// the host loop:
+//   pxf_fan_search  every ray iterates {rotate, flat if still free and not grazing, range test} until it meets
+//                   a grating; the round index goes to `it_hit`, the largest one to `*imax` (the host loop's
+//                   round count), rays that exhaust `cap` rounds are counted in `*nmiss`.
+//   pxf_fan_finish  every ray replays the rounds after its own: diffract once (reflect + radgrat) at the
+//                   start of round it_hit+1, then keep rotating with the bundle up to round imax (the host
+//                   loop rotates ALL rays every round and undoes `imax` rotations at the end).
+// Two launches, 2 x 144 B/ray of HBM traffic; fp64-VALU-bound (a rotation of nine components, an fp32-rounded
+// propagation and a square root per round; the asin of the grazing test is only evaluated within 1e-9 of
+// its threshold).
+#include <math.h>
+
+#include "pxf_kernel.h"
+#include "pxf_ops_surfaces.h"
+#include "pxf_ops_transforms.h"
+
+namespace pxf {
+
+struct FanGeom {
+    double lo, hi, thr;  // grating radial extent (hubdist, hubdist + length) and the grazing threshold [rad]
+    double s_lo, s_hi;   // sin(thr) (1 -+ 1e-9): outside this band |asin n| > thr is decided without the asin
+    TransformOp<false> rot;
+    int cap;
+};
+
+// abs(arcsin(n)) > thr  (sector.py:669,693).  asin is monotone and ocml's is accurate to a few ulp, so for
+// |n| outside [s_lo, s_hi] the comparison is decided by |n| alone; only a ray within 1e-9 (relative) of the
+// threshold pays for the asin -- and gets exactly the driver's answer.
+__device__ __forceinline__ bool fan_not_grazing(double n, const FanGeom &g)
+{
+    const double a = fabs(n);
+    if (a > g.s_hi) return true;
+    if (a < g.s_lo) return false;
+    return fabs(asin(n)) > g.thr;  // (NaN lands here: false, as in the driver)
+}
+
+// the range test of sector.py:672-673,698-699:  rho = -sqrt(x^2+y^2)*sign(y);  lo < rho < hi
+__device__ __forceinline__ bool fan_in_range(const double *c, double lo, double hi)
+{
+    const double y = c[Y];
+    const double sgn = y > 0. ? 1. : (y < 0. ? -1. : y);  // sign(0) = 0, sign(NaN) = NaN
+    const double rho = -sqrt(c[X] * c[X] + c[Y] * c[Y]) * sgn;
+    return rho > lo && rho < hi;
+}
+
+__device__ __forceinline__ void load9(const Cols &c, int64_t i, Ray &r)
+{
+#pragma unroll
+    for (int col = X; col <= UZ; col++) r.c[col] = c.p[col][i];
+}
+__device__ __forceinline__ void store9(const Cols &c, int64_t i, const Ray &r)
+{
+#pragma unroll
+    for (int col = X; col <= UZ; col++) c.p[col][i] = r.c[col];
+}
+
+__global__ __launch_bounds__(kBlock) void fan_search_kernel(Cols c, int64_t num, FanGeom g, int32_t *__restrict__ it_hit,
+                                                            int32_t *__restrict__ imax, unsigned long long *__restrict__ nmiss)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+        Ray r[1];
+        load9(c, i, r[0]);
+        const bool sel[1] = {true};
+        unsigned wm[1];
+        // round 0: the bundle as it arrives
+        if (fan_not_grazing(r[0].c[N], g)) FlatOp<false>{0.}.apply<1>(r, sel, wm);
+        bool hit = fan_in_range(r[0].c, g.lo, g.hi);
+        int it = 0;
+        while (!hit && it < g.cap) {
+            it++;
+            g.rot.apply<1>(r, sel, wm);
+            if (fan_not_grazing(r[0].c[N], g)) FlatOp<false>{0.}.apply<1>(r, sel, wm);
+            hit = fan_in_range(r[0].c, g.lo, g.hi);
+        }
+        store9(c, i, r[0]);
+        it_hit[i] = hit ? it : -1;
+        if (hit)
+            atomicMax(imax, it);
+        else
+            atomicAdd(nmiss, 1ull);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fan_finish_kernel(Cols c, int64_t num, TransformOp<false> rot, RadgratOp<false> grat,
+                                                            const int32_t *__restrict__ it_hit, int imax)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+        const int it = it_hit[i];
+        if (it < 0) continue;  // never met a grating (reported by the search): left as it stands
+        Ray r[1];
+        load9(c, i, r[0]);
+        const bool sel[1] = {true};
+        unsigned wm[1];
+        bool pending = true;
+        for (int j = it + 1; j <= imax; j++) {
+            if (pending) {
+                ReflectOp{}.apply<1>(r, sel, wm);
+                grat.apply<1>(r, sel, wm);
+                pending = false;
+            }
+            rot.apply<1>(r, sel, wm);
+        }
+        if (pending) {  // met its grating in the last round: sector.py:703-704
+            ReflectOp{}.apply<1>(r, sel, wm);
+            grat.apply<1>(r, sel, wm);
+        }
+        store9(c, i, r[0]);
+    }
+}
+
+static int fan_cols(double *const *cols, Cols &c)
+{
+    if (!cols) return PXF_EINVAL;
+    for (int col = X; col <= UZ; col++) {
+        if (!cols[col]) return PXF_EINVAL;
+        c.p[col] = cols[col];
+    }
+    return PXF_OK;
+}
+
+static TransformOp<false> fan_rotation(double ang)
+{
+    double cs[6];
+    // tran.transform(rays, 0, 0, 0, ang, 0, 0): the wrapper negates its arguments (transformations.py:29); the
+    // integer zeros of that call stay +0.0
+    trig6(-ang, 0., 0., false, cs);
+    return TransformOp<false>{0., 0., 0., cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], 7};
+}
+
+}  // namespace pxf
+
+using namespace pxf;
+
+extern "C" {
+
+int pxf_fan_search(double *const *cols, int64_t num, double hubdist, double length, double ang, double thr, int32_t cap,
+                   int32_t *it_hit, int32_t *imax, uint64_t *nmiss, pxf_stream_t stream)
+{
+    Cols c{};
+    int rc = fan_cols(cols, c);
+    if (rc != PXF_OK) return rc;
+    if (num < 0 || cap < 0 || !it_hit || !imax || !nmiss) return PXF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(imax, 0, sizeof(int32_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(nmiss, 0, sizeof(uint64_t), s);
+    if (e != hipSuccess) return hip_fail(e);
+    if (num == 0) return PXF_OK;
+    const double st = sin(thr);
+    FanGeom g{hubdist, length + hubdist, thr, st * (1 - 1e-9), st * (1 + 1e-9), fan_rotation(ang), cap};
+    hipLaunchKernelGGL(fan_search_kernel, dim3(grid_for(num)), dim3(kBlock), 0, s, c, num, g, it_hit, imax,
+                       reinterpret_cast<unsigned long long *>(nmiss));
+    e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+int pxf_fan_finish(double *const *cols, int64_t num, double ang, double dpermm, double order, double wave,
+                   const int32_t *it_hit, int32_t imax, pxf_stream_t stream)
+{
+    Cols c{};
+    int rc = fan_cols(cols, c);
+    if (rc != PXF_OK) return rc;
+    if (num < 0 || imax < 0 || !it_hit) return PXF_EINVAL;
+    if (num == 0) return PXF_OK;
+    RadgratOp<false> grat{dpermm, order, wave, 0., 0.};
+    radgrat_consts(grat.S, grat.C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fan_finish_kernel, dim3(grid_for(num)), dim3(kBlock), 0, s, c, num, fan_rotation(ang), grat, it_hit,
+                       (int)imax);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PXF_OK : hip_fail(e);
+}
+
+}  // extern "C"

@@ -43,3 +43,53 @@ def eta(phi0, theta0):
 def yaw(phi0, theta0):
     """Yaw from the polar pair (phi0, theta0)."""
     return np.arctan(np.sin(theta0) / np.tan(phi0))
+
+
+def fanArray(rays, hubdist, length, ang, dpermm, order, wave, thr=.001, coords=None, maxiter=100000):
+    """A fanned array of radial gratings about a common hub, per ray, on the device (EXTENSION: the reference
+    has no such function -- it is the `while` loop of its examples/arcus/sector.py:663-704, `gratArray`).
+
+    Equivalent, bit for bit, to this loop through the drop-in API (rays already in the frame of the first
+    grating, hub at the origin)::
+
+        indg = abs(arcsin(n)) > thr;  flat(rays, ind=indg)
+        rho = -sqrt(x**2 + y**2) * sign(y);  ind = (rho > hubdist) & (rho < length + hubdist)
+        ind2 = prev = ind;  i = 0
+        while prev.sum() < len(x):
+            i += 1
+            reflect(rays, ind=ind2);  radgrat(rays, dpermm, order, wave, ind=ind2)
+            transform(rays, 0, 0, 0, ang, 0, 0, coords=coords)
+            flat(rays, ind=~prev & (abs(arcsin(n)) > thr))
+            rho = ...;  ind = ...;  ind2 = ~prev & ind;  prev = prev | ind
+        reflect(rays, ind=ind2);  radgrat(rays, dpermm, order, wave, ind=ind2)
+
+    which costs a dozen passes over the bundle and a host synchronisation per grating row (~226 rows for the
+    Arcus petal); here every ray walks the fan in registers with the same device code (two launches).
+    Returns i, the number of rows walked (the caller undoes `ang * i` of rotation, sector.py:718)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _fused as fused
+    from . import _lib, native
+    from . import transformations as tran
+    fused.flush()
+    cols = list(rays[1:10])
+    num, dev = native._check_cols(cols, "fanArray")
+    it_hit = torch.empty(max(num, 1), dtype=torch.int32, device=dev)
+    scal = torch.zeros(4, dtype=torch.int32, device=dev)           # [imax | pad | nmiss (uint64)]
+    ptrs = (C.c_void_p * 10)(None, *[t.data_ptr() for t in cols])
+    h, st = _lib.lib(), native._stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(h.pxf_fan_search(ptrs, num, float(hubdist), float(length), float(ang), float(thr), int(maxiter),
+                                    it_hit.data_ptr(), scal.data_ptr(), scal[2:].data_ptr(), st), "pxf_fan_search")
+        imax, _, miss_lo, miss_hi = [int(v) for v in scal.tolist()]          # the one sync: the row count is data-dependent
+        if miss_lo or miss_hi:
+            raise RuntimeError("fanArray: %d rays never reached a grating within %d rows"
+                               % (miss_lo + (miss_hi << 32), maxiter))
+        _lib.check(h.pxf_fan_finish(ptrs, num, float(ang), float(dpermm), float(order), float(wave), it_hit.data_ptr(),
+                                    imax, st), "pxf_fan_finish")
+    if coords is not None:
+        for _ in range(imax):
+            tran.update_coords(coords, 0, 0, 0, ang, 0, 0)
+    return imax

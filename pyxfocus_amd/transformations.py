@@ -84,15 +84,20 @@ def transform(rays, dx, dy, dz, rx, ry, rz, ind=None, coords=None):
     mask = ind_to_mask(ind, x.shape[0], _dev(rays))
     tran.transform(x, y, z, l, m, n, ux, uy, uz, -dx, -dy, -dz, -rx, -ry, -rz, mask=mask)
     if coords is not None:
-        rotm = rotationM(rx, ry, rz)
-        tranm = translationM(dx, dy, dz)
-        rotmi = rotationM(rx, ry, rz, inverse=True)
-        tranmi = translationM(-dx, -dy, -dz)
-        coords[0] = np.dot(rotm, coords[0])
-        coords[1] = np.dot(np.dot(rotm, tranm), coords[1])
-        coords[2] = np.dot(coords[2], rotmi)
-        coords[3] = np.dot(coords[3], np.dot(tranmi, rotmi))
+        update_coords(coords, dx, dy, dz, rx, ry, rz)
     return
+
+
+def update_coords(coords, dx, dy, dz, rx, ry, rz):
+    """The 4x4 bookkeeping of one transform() (transformations.py:32-42), without touching any ray."""
+    rotm = rotationM(rx, ry, rz)
+    tranm = translationM(dx, dy, dz)
+    rotmi = rotationM(rx, ry, rz, inverse=True)
+    tranmi = translationM(-dx, -dy, -dz)
+    coords[0] = np.dot(rotm, coords[0])
+    coords[1] = np.dot(np.dot(rotm, tranm), coords[1])
+    coords[2] = np.dot(coords[2], rotmi)
+    coords[3] = np.dot(coords[3], np.dot(tranmi, rotmi))
 
 
 def itransform(rays, dx, dy, dz, rx, ry, rz, coords=None, ind=None):

@@ -205,3 +205,29 @@ def test_config5_spo_stage_segmented_equals_shell_loop(fast):
     # device Philox source: the same distribution, shell by shell (mean radius of every shell)
     c = A.defineSPOaperture_segmented(N, source="philox", seed=3, **kw)
     assert np.isfinite(c[0][1].cpu().numpy()).all() and abs(float(c[1].sum()) / float(b[1].sum()) - 1) < 1e-3
+
+
+def test_config5_fan_array_equals_host_loop_and_reference_fixture(golden):
+    """grating.fanArray (every ray walks the fanned grating array in registers: two launches) against
+    (a) the reference's stacked-grating `while` loop through the drop-in API (gratArray of
+    examples/arcus_sector.py): bit-identical rays, same row count, same coords, same focusY shift;
+    (b) the fixture the loop produced on the reference's own Python modules (config5.npz)."""
+    import arcus_sector as A
+    from pyxfocus_amd import grating
+    g = golden["config5"]
+    kw = dict(order=int(g["par/order"]), wave=float(g["par/wave"]), shell_stride=int(g["par/shell_stride"]),
+              modules_per_row=int(g["par/modules_per_row"]))
+    np.random.seed(int(g["par/seed"]))
+    a = A.traceArcus(A.Api.amd(), int(g["par/N"]), **kw)
+    np.random.seed(int(g["par/seed"]))
+    b = A.traceArcus(A.Api.amd(), int(g["par/N"]), fan=grating.fanArray, **kw)
+    assert a["grating_rows"] == b["grating_rows"] == int(g["grating_rows"]) and a["dz"] == b["dz"]
+    assert np.array_equal(np.array(a["coords"]), np.array(b["coords"]))
+    for k, u, v in zip(ALLCOLS, host(a["rays"]), host(b["rays"])):
+        assert bits_equal(u, v).all(), k
+    _check_focal(b, [g["out/" + k] for k in ALLCOLS], g["weights"], float(g["dz"]), int(g["grating_rows"]), g["coords"])
+    # a ray that can never reach a grating is reported, not looped on forever
+    rays = [t.clone() for t in b["rays"]]
+    rays[1].fill_(0.); rays[2].fill_(0.); rays[4].fill_(0.); rays[5].fill_(0.); rays[6].fill_(1.)
+    with pytest.raises(RuntimeError, match="never reached a grating"):
+        grating.fanArray(rays, 1e4, 95., 1e-4, .016, -3, 2.4, maxiter=50)
