@@ -26,6 +26,8 @@ and the outputs the reference produced for them.  No reference source text is st
                      own NumPy code can have produced a recorded number.
   alignment.npz      examples/single_pass_alignment.py (examples/axro/singlePassAlignment.py:20-190) through the
                      reference's own modules: Zernike wavefront (OPD), misaligned primary / pair, applyT, centroids.
+  ws_heights.npz     examples/ws_axial_heights.py (examples/axro/axialHeights.py:50-133) through the reference's own
+                     modules: W-S radius probes, off-axis W-S pair, focusI, hpd, rmsCentroid.
   config5.npz        a small Arcus-style multi-shell trace (sector.py:540-757 call shape) through
                      the reference's own surfaces.py / transformations.py / analyses.py wrappers
                      over the compiled Fortran: per-shell SPO pair, grating stage, focusY.
@@ -289,18 +291,41 @@ def gold_alignment(tran, src, anal, surf):
         len(rays[1]), blob["primary/cen"][0, 0], blob["primary/cen"][1, 0], cen[0, 0], cen[1, 0]))
 
 
+def gold_ws_heights(tran, src, anal, surf):
+    """examples/ws_axial_heights.py (the reference's examples/axro/axialHeights.py:50-133) on the reference's
+    own modules: one-ray radius probes, a W-S pair with an off-axis kick, focusI, hpd, rmsCentroid."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import ws_axial_heights as W
+    a = W.Api(src, surf, tran, anal, np, sys.modules["PyXFocus.conicsolve"])
+    blob = {"prim_z": np.array([1e4 + 50., 1e4 + 150., 1e4 + 250.]), "sec_z": np.array([1e4 - 50., 1e4 - 150., 9750.])}
+    blob["primrad"] = np.array([W.wsPrimrad(a, z, 220., 1e4, psi) for z in blob["prim_z"] for psi in (1., .6)])
+    blob["secrad"] = np.array([W.wsSecrad(a, z, 220., 1e4, psi) for z in blob["sec_z"] for psi in (1., .6)])
+    for tag, kw in (("onaxis", dict(offaxis=0.)), ("offaxis", dict(offaxis=1e-4)), ("zeta", dict(offaxis=5e-5, psi=.7))):
+        np.random.seed(3)
+        smin, smax, f, hpd, rms, rays = W.traceZeta(a, 1e4 + 50., num=4000, **kw)
+        blob[tag + "/scalars"] = np.array([smin, smax, f, hpd, rms])
+        for k, v in zip(cases.ALLCOLS, rays):
+            blob["%s/%s" % (tag, k)] = v
+    np.random.seed(4)
+    blob["merit"] = np.array(W.onaxisMerit(a, 1e4 + 50., float(blob["onaxis/scalars"][1]), num=1500), dtype=float)
+    np.savez_compressed(os.path.join(OUT, "ws_heights.npz"), **blob)
+    print("ws_heights: primrad %s, traceZeta(onaxis) %s" % (blob["primrad"][:2], blob["onaxis/scalars"]))
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5, alignment")
+    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5, alignment, ws_heights")
     only = [t for t in ap.parse_args().only.split(",") if t]
     os.makedirs(OUT, exist_ok=True)
     ref = api.load_ref()
     tran, src = shim_reference_python(ref)
-    if not only or "analyses" in only or "config5" in only or "alignment" in only:
+    if not only or set(only) & {"analyses", "config5", "alignment", "ws_heights"}:
         anal, surf = shim_reference_analyses(ref)
         if not only or "alignment" in only:
             gold_alignment(tran, src, anal, surf)
+        if not only or "ws_heights" in only:
+            gold_ws_heights(tran, src, anal, surf)
         if not only or "analyses" in only:
             gold_analyses(ref, tran, anal, surf)
         if not only or "config5" in only:

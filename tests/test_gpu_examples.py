@@ -153,3 +153,31 @@ def test_single_pass_alignment_example_equals_reference_python(golden):
             want = g["%s/%s" % (tag, k)]
             tol = 1e-9 if k in "xyz" else (1e-11 if k == "opd" else 1e-12)
             assert np.abs(v.cpu().numpy() - want).max() <= tol * (1 + np.abs(want).max()), (tag, k)
+
+
+def test_ws_axial_heights_example_equals_reference_python(golden):
+    """examples/ws_axial_heights.py on pyxfocus_amd against the fixture the SAME code produced on the
+    reference's own modules (ws_heights.npz).  Wolter-Schwarzschild surfaces are tolerance parity: primaries
+    ~1e-11 mm; a secondary's converged z carries the reference's own (1 - cos beta) conditioning:
+    a few 1e-9 mm for a few rays in a thousand.  Radius probes 1e-10 mm; strike heights, focus shift, HPD and
+    RMS follow."""
+    import ws_axial_heights as W
+    g = golden["ws_heights"]
+    api = W.Api.amd()
+    got = np.array([W.wsPrimrad(api, z, 220., 1e4, psi) for z in g["prim_z"] for psi in (1., .6)])
+    assert np.abs(got - g["primrad"]).max() < 1e-10, np.abs(got - g["primrad"]).max()
+    got = np.array([W.wsSecrad(api, z, 220., 1e4, psi) for z in g["sec_z"] for psi in (1., .6)])
+    assert np.abs(got - g["secrad"]).max() < 2e-8, np.abs(got - g["secrad"]).max()
+    for tag, kw in (("onaxis", dict(offaxis=0.)), ("offaxis", dict(offaxis=1e-4)), ("zeta", dict(offaxis=5e-5, psi=.7))):
+        np.random.seed(3)
+        smin, smax, f, hpd, rms, rays = W.traceZeta(api, 1e4 + 50., num=4000, **kw)
+        want = g[tag + "/scalars"]
+        assert abs(smin - want[0]) < 2e-8 and abs(smax - want[1]) < 2e-8, tag
+        assert abs(f - want[2]) < 1e-6 * max(1., abs(want[2])) and abs(hpd - want[3]) < 1e-8 and abs(rms - want[4]) < 1e-8, (
+            tag, f, hpd, rms, want)
+        for k, v in zip(ALLCOLS, rays):
+            w = g["%s/%s" % (tag, k)]
+            assert np.abs(v.cpu().numpy() - w).max() <= 2e-8 * (1 + np.abs(w).max()), (tag, k)
+    np.random.seed(4)
+    nout, zmean = W.onaxisMerit(api, 1e4 + 50., float(g["onaxis/scalars"][1]), num=1500)
+    assert nout == int(g["merit"][0]) and abs(zmean - g["merit"][1]) < 2e-8
