@@ -182,9 +182,10 @@ int pxf_wssecondaryback(double *x, double *y, double *z, const double *l, const 
 /* ---- zernsurf.f95 (+ zernset, specialFunctions.f95:142-232) ------------------------------- */
 
 /* tracezern(x,...,uz,num,coeff,rorder,aorder,arrsize,rad)   zernsurf.f95:8-101
- * coeff/rorder/aorder are HOST arrays of length arrsize (they are folded on the host into a
- * per-(n,|m|) table that the kernel stages in LDS).  aorder<0 -> sin, >0 -> cos, 0 -> radial
- * term.  Orders up to n=15 are supported (PXF_ERANGE beyond). */
+ * coeff/rorder/aorder are HOST arrays of length arrsize (they are expanded on the host into the
+ * monomial coefficients of ONE bivariate polynomial -- pxf_zernike_monomials -- which the kernel stages
+ * in LDS and evaluates by Horner schemes).  aorder<0 -> sin, >0 -> cos, 0 -> radial term.  Orders up to
+ * n=15 are supported (PXF_ERANGE beyond). */
 int pxf_tracezern(double *x, double *y, double *z, const double *l, const double *m, const double *n,
                   double *ux, double *uy, double *uz, int64_t num, const double *coeff,
                   const int32_t *rorder, const int32_t *aorder, int32_t arrsize, double rad,

@@ -83,9 +83,6 @@ __device__ __forceinline__ void zern_eval(const double *__restrict__ t, double x
 // conic"; the reference's zernsurf is a pure Zernike sag): the sag of a conic of radius
 // R and constant K is added under the Zernike sum,  F = z - c rho^2/(1+sqrt(1-(K+1) c^2 rho^2)) - S.
 // Parity unpinned; checked against the conic kernel (coeff = 0) and an independent NumPy Newton.
-#ifdef PXF_ZERN_MIN_WAVES_ALL   // dev builds (tools/zern_repro.sh): one occupancy target for every order
-#define PXF_ZERN_MIN_WAVES(NMAX) PXF_ZERN_MIN_WAVES_ALL
-#endif
 #ifndef PXF_ZERN_MIN_WAVES
 // >= 2 waves per SIMD keeps a kernel within 256 registers per lane, so the compiler has no AGPRs to spill
 // into: its VGPR->AGPR "Reload Reuse" path can drop half of a 64-bit copy (profiles/r02_zernike_miscompile.md).
