@@ -178,6 +178,14 @@ int pxf_wsprimaryback(double *x, double *y, double *z, const double *l, const do
 int pxf_wssecondaryback(double *x, double *y, double *z, const double *l, const double *m, const double *n,
                         double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
                         double thick, const uint8_t *mask, pxf_stream_t stream);
+/* Host utility (no GPU): beta = atan2(r, z), cos(beta) and tan(beta/2) exactly as the Wolter-Schwarzschild
+ * secondary kernels form them -- a restatement of the x86-64 C library's table-driven cosine and of its
+ * small-argument tangent polynomial, whose rounding the reference's `(1 - cos(beta))` (woltsurf.f95:518-519)
+ * amplifies to 2.6e-9 mm per ulp.  NaN where the pair lies outside the routines' range (r/z >= 1.15, z <= 0;
+ * tan: beta/2 >= 0.0607): the kernels then use the correctly rounded quotient / the half-angle identity.
+ * Exported so that a CPU test can hold them to libm's atan2 / cos / tan bit for bit. */
+int pxf_host_cos_atan2(const double *r, const double *z, double *beta, double *cosbeta, double *tanhalf,
+                       int64_t num);
 
 /* ---- zernsurf.f95 (+ zernset, specialFunctions.f95:142-232) ------------------------------- */
 

@@ -1415,3 +1415,16 @@ int32_t orc_reconstruct(double *xang, double *yang, int32_t xdim, int32_t ydim, 
     }
     return sweeps;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* beta = atan2(r, z), cos(beta), tan(beta/2) by the C library -- the calls woltsurf.f95:510,      */
+/* 516-520 make per Newton step of the W-S secondary; checker of the product's               */
+/* pxf_host_cos_atan2.                                                                         */
+void orc_cos_atan2(const double *r, const double *z, double *beta, double *cosbeta, double *tanhalf, int64_t num)
+{
+    for (int64_t i = 0; i < num; i++) {
+        beta[i] = atan2(r[i], z[i]);
+        cosbeta[i] = cos(beta[i]);
+        tanhalf[i] = tan(beta[i] / 2);
+    }
+}

@@ -20,8 +20,16 @@
 #include <stdlib.h>
 
 #include "pxf_kernel.h"
+#include "pxf_libm_match.h"
 
 namespace pxf {
+
+// sin/cos/tan(k/128) head+tail tables of pxf_libm_match.h: constant memory for the kernels, a host copy for
+// the pxf_host_cos_atan2 utility
+__constant__ double c_sincos_tab[4 * PXF_TRIG_TAB_N] = PXF_SINCOS_TAB_INIT;
+__constant__ double c_tan_tab[2 * PXF_TRIG_TAB_N] = PXF_TAN_TAB_INIT;
+static const double h_sincos_tab[4 * PXF_TRIG_TAB_N] = PXF_SINCOS_TAB_INIT;
+static const double h_tan_tab[2 * PXF_TRIG_TAB_N] = PXF_TAN_TAB_INIT;
 
 // ---- woltersine : woltsurf.f95:167-215 --------------------------------------------------------
 struct WolterSineOp {
@@ -366,11 +374,19 @@ struct WSOp {
                     const double sb = rr / qq;                 // sin of beta = atan2(rr, z)
                     // cos(beta) must carry the reference's OWN rounding: its `a` holds (1 - cos beta) with
                     // cos beta ~ 1 - 3e-4, so one ulp of cos beta moves the converged z by ~2.6e-9 mm (1e-16 /
-                    // 3e-4 x 8400 mm).  glibc's cos(atan2(rr, z)) is the correctly rounded cosine of the
-                    // angle of the DOUBLES (rr, z) in all but ~1e-3 of the cases, so that is what is
-                    // formed here: z / sqrt(rr^2 + z^2) in double-double, rounded once.
-                    const double cb = cos_of_ratio_rn(rr, z);
-                    const bool flag = cb >= cbs;              // beta <= betas
+                    // 3e-4 x 8400 mm).  glibc's cos is not correctly rounded (~5e-4 of its results are the other
+                    // neighbour), so it is restated operation by operation (pxf_libm_match.h: beta as the
+                    // correctly rounded arctangent, then the library's table + polynomial cosine).  Outside that
+                    // routine's range the correctly rounded quotient z / sqrt(rr^2 + z^2) stands in.
+                    double beta = 0., cb;
+                    bool flag;
+                    const bool matched = libm_cos_atan2(rr, z, c_sincos_tab, c_tan_tab, beta, cb);
+                    if (matched) {
+                        flag = beta <= betas;
+                    } else {
+                        cb = cos_of_ratio_rn(rr, z);
+                        flag = cb >= cbs;                     // beta <= betas
+                    }
                     if (flag) {
                         F = -z + cbs * ff;  // cos(betas) / a, a = 1/ff
                         const double dadbs = sbs / ff / (1 - cbs) + (k + 1) * (cbs + 1) * tb2s / (cb2s * cb2s) / 2 / g / k;
@@ -381,7 +397,10 @@ struct WSOp {
                         Fy = -2. / tbs * y / rr;
                         Fz = gam - 1.;
                     } else {
-                        const double t = sb / (1 + cb);          // tan(beta/2)
+                        // tan(beta/2): the library's own polynomial where it applies (kterm cancels to ~1e-10 at the
+                        // mirror's edge, see pxf_libm_match.h), else the half-angle identity
+                        const double hb = .5 * beta;
+                        const double t = (matched && hb > 2e-8 && hb < 0.0607) ? libm_tan_small(hb) : sb / (1 + cb);
                         const double kterm = (1 / k) * (t * t) - 1;
                         const double p1 = pow(kterm, 1 + k), pkk = p1 / kterm;  // kterm**(1+k), kterm**k
                         const double a = (1 - cb) / (1 - cbs) / ff + (1 + cb) / (2 * g) * p1;
@@ -831,6 +850,18 @@ int pxf_legsurf(const double *x, const double *y, double *l, double *m, double *
     c.p[M] = m;
     c.p[N] = n;
     return launch_rays(c, num, mask, stream, op);
+}
+
+int pxf_host_cos_atan2(const double *r, const double *z, double *beta, double *cosbeta, double *tanhalf,
+                       int64_t num)
+{
+    if (num < 0 || (num > 0 && (!r || !z || !beta || !cosbeta || !tanhalf))) return PXF_EINVAL;
+    for (int64_t i = 0; i < num; i++) {
+        if (!libm_cos_atan2(r[i], z[i], h_sincos_tab, h_tan_tab, beta[i], cosbeta[i])) beta[i] = cosbeta[i] = NAN;
+        const double hb = .5 * beta[i];
+        tanhalf[i] = (hb > 2e-8 && hb < 0.0607) ? libm_tan_small(hb) : NAN;
+    }
+    return PXF_OK;
 }
 
 int pxf_wsprimary(double *x, double *y, double *z, const double *l, const double *m, const double *n,

@@ -297,3 +297,45 @@ def test_zernike_monomial_expansion_matches_reference_zernset(port, nmax):
     # relative to sum |coeff| x n^2 (the natural size of a gradient): 1e-13 up to degree 10 (the kernels'
     # Cartesian range), 1e-10 at 15 (not used there: orders 11..15 stay on the polar recurrences)
     assert worst < (1e-13 if nmax <= 10 else 1e-10), worst
+
+
+def test_ws_secondary_cos_beta_matches_libm_bitwise():
+    """The Wolter-Schwarzschild secondary's `(1 - cos(beta))`, beta = atan2(r, z), turns one ulp of the C
+    library's cosine into 2.6e-9 mm, and that cosine is not correctly rounded -- so the
+    kernels restate it, and the library's tangent polynomial for `tan(beta/2)` (pxf_libm_match.h).  Host copy
+    of the very same routines (pxf_host_cos_atan2) against the C library on THIS machine (oracle.orc_cos_atan2 =
+    libm's atan2, cos, tan -- the calls woltsurf.f95:510-520 makes): cosine and tangent bit for bit for every
+    beta libm and the restatement agree on (the restated arctangent is the correctly rounded one, libm's is
+    that in all but ~2e-3 of the cases), and the composition cos(atan2(r, z)) in all but 5e-4 of the cases over
+    the whole range, 1e-4 in the W-S range."""
+    import ctypes as C
+    from oracle import api
+    from pyxfocus_amd import _lib
+    olib = C.CDLL(os.path.join(os.path.dirname(api.__file__), "libpxf_oracle.so"))
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(77)
+    n = 400_000
+    for lo, hi, max_cos_miss in ((1e-3, 0.05, 1e-4), (1e-6, 1.14, 5e-4)):
+        z = 8000. + 800. * rng.random(n)
+        r = z * (lo + (hi - lo) * rng.random(n))
+        b_ref, c_ref, t_ref, b_got, c_got, t_got = (np.empty(n) for _ in range(6))
+        olib.orc_cos_atan2(r.ctypes.data_as(dp), z.ctypes.data_as(dp), b_ref.ctypes.data_as(dp),
+                           c_ref.ctypes.data_as(dp), t_ref.ctypes.data_as(dp), C.c_int64(n))
+        assert _lib.lib().pxf_host_cos_atan2(r.ctypes.data_as(dp), z.ctypes.data_as(dp), b_got.ctypes.data_as(dp),
+                                             c_got.ctypes.data_as(dp), t_got.ctypes.data_as(dp), n) == 0
+        inside = ~np.isnan(b_got)
+        assert inside.mean() > 0.74 and np.array_equal(inside, b_ref < 0.85546875)
+        same_beta = inside & (b_got == b_ref)
+        assert same_beta.sum() > 0.995 * inside.sum()
+        assert np.abs(b_got[inside] - b_ref[inside]).max() <= 1.2e-16          # never more than the neighbour
+        assert np.array_equal(c_got[same_beta], c_ref[same_beta])              # the cosine routine: bit for bit
+        assert (c_got[inside] != c_ref[inside]).mean() < max_cos_miss
+        tin = same_beta & ~np.isnan(t_got)
+        assert np.array_equal(~np.isnan(t_got), inside & (b_got / 2 < 0.0607)) and tin.sum() > 1000
+        assert np.array_equal(t_got[tin], t_ref[tin])                          # the tangent polynomial: bit for bit
+    # outside the routines' range: NaN (the kernels then use the correctly rounded quotient)
+    r = np.array([1., 2., 1., 0.]); z = np.array([0., 1., -1., 1.])
+    b, c, t = np.empty(4), np.empty(4), np.empty(4)
+    assert _lib.lib().pxf_host_cos_atan2(r.ctypes.data_as(dp), z.ctypes.data_as(dp), b.ctypes.data_as(dp),
+                                         c.ctypes.data_as(dp), t.ctypes.data_as(dp), 4) == 0
+    assert np.isnan(b).all() and np.isnan(c).all() and np.isnan(t).all()
