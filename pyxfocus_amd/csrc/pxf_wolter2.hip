@@ -72,6 +72,7 @@ struct WolterSineOp {
 
 // ---- Legendre-Legendre deformed mirrors --------------------------------------------------------
 constexpr int kLLMax = 256;  // (max axial + 1) * (max az + 1)
+constexpr int kLLRows = 32;  // register form: at most this many (padded) axial rows
 
 struct LLData {
     double twop, pp, cst;    // primary
@@ -80,22 +81,27 @@ struct LLData {
     double tol, zmid, zhalf;  // Newton tolerance, (zmax+zmin)/2, (zmax-zmin)/2
     double dphi, zspan;      // dphi, zmax-zmin
     int ka, kt;              // highest axial / azimuthal order present
-    double cmat[kLLMax];     // C[i*(kt+1)+j], by value in the kernel-argument segment
+    int rows, stride;        // layout of cmat: C[i*stride + j]; rows = ka+1 (generic) or padded to even (register form)
+    double cmat[kLLMax];     // by value in the kernel-argument segment
+    double za[kLLRows], zb[kLLRows];  // (2n+3)/(n+2), (n+1)/(n+2): P_{n+2} = za_n x P_{n+1} - zb_n P_n
 };
 
 // KIND: 0 primary (:220-288), 1 secondary (:293-379), 2 ellipsoid (:643-718).
-// KTMAX >= 0: the azimuthal orders are known to be <= KTMAX, so P_j(t), P'_j(t) are generated ONCE
-// per Newton step into registers (fully unrolled) and the double sum costs two multiply-adds per
-// matrix cell (fused; these surfaces are tolerance-parity); KTMAX < 0: any order, the t-recurrence
-// is regenerated for every axial order.
+// KTMAX >= 0 ("register form"): the azimuthal orders are known to be <= KTMAX.  The host pads the matrix to
+// KTMAX+1 columns and an even number of rows with zeros, so the double sum has NO data-dependent control
+// flow: P_j(t), P'_j(t) are generated once per Newton step into registers (fully unrolled, compile-time
+// recurrence coefficients), the coefficients come straight from the kernel-argument segment through
+// wave-uniform SCALAR loads (an SGPR pair is one operand of v_fma_f64) -- no LDS traffic at all -- and two
+// axial orders run per trip as four independent FMA chains.  (Round 1-2 staged the matrix in LDS: four SIMDs
+// reading one ds_read_b64 per two FMAs made the LDS pipe, not the fp64 pipe, the bound: 54 % VALU issue.)
+// KTMAX < 0: any order; matrix in LDS, the t-recurrence regenerated for every axial order.
 template <int KIND, int KTMAX = -1>
 struct LLOp : LLData {
     static constexpr int MAXV = 1;
     static constexpr unsigned RD = POS | DIR;
     static constexpr unsigned WR = POS | NRM;
 
-    // LDS: [0,kLLMax) the matrix C, then the recurrence coefficients a_n=(2n+3)/(n+2), b_n=(n+1)/(n+2)
-    // of P_{n+2} = a_n x P_{n+1} - b_n P_n (so the inner loops multiply instead of dividing)
+    // LDS (generic form only): [0,kLLMax) the matrix C, then the recurrence coefficients a_n, b_n
     __device__ __forceinline__ double *lds() const
     {
         __shared__ double s_c[3 * kLLMax];
@@ -103,21 +109,21 @@ struct LLOp : LLData {
     }
     __device__ __forceinline__ void prologue() const
     {
-        double *s = lds();
-        const int nn = (ka + 1) * (kt + 1);
-        for (int i = threadIdx.x; i < nn; i += kBlock) s[i] = cmat[i];
-        for (int i = threadIdx.x; i < kLLMax; i += kBlock) {
-            s[kLLMax + i] = (double)(2 * i + 3) / (double)(i + 2);
-            s[2 * kLLMax + i] = (double)(i + 1) / (double)(i + 2);
+        if constexpr (KTMAX < 0) {
+            double *s = lds();
+            const int nn = (ka + 1) * (kt + 1);
+            for (int i = threadIdx.x; i < nn; i += kBlock) s[i] = cmat[i];
+            for (int i = threadIdx.x; i < kLLMax; i += kBlock) {
+                s[kLLMax + i] = (double)(2 * i + 3) / (double)(i + 2);
+                s[2 * kLLMax + i] = (double)(i + 1) / (double)(i + 2);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     template <int V>
     __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
     {
-        const double *__restrict__ cm = lds();
-        const double *__restrict__ ra = cm + kLLMax, *__restrict__ rb = cm + 2 * kLLMax;
         double *c = r[0].c;
         double Fx = 0., Fy = 0., Fz = 0.;
         bool act = sel[0];
@@ -133,9 +139,9 @@ struct LLOp : LLData {
             const bool zin = !(fabs(zarg) > 1.), tin = !(fabs(targ) > 1.);
             double add = 0., addt = 0., addzz = 0.;
             double pz0 = 1., pz1 = zc, dz0 = 0., dz1 = 1.;  // P_i, P_{i+1}, P'_i, P'_{i+1} in zarg
-            constexpr int NT_ = KTMAX >= 0 ? KTMAX + 1 : 1;
-            double Pt[NT_], Dt[NT_];
             if constexpr (KTMAX >= 0) {
+                constexpr int NT_ = KTMAX + 1;
+                double Pt[NT_], Dt[NT_];
                 Pt[0] = 1.;
                 Dt[0] = 0.;
                 if constexpr (KTMAX >= 1) {
@@ -144,56 +150,44 @@ struct LLOp : LLData {
                 }
 #pragma unroll
                 for (int j = 0; j + 2 <= KTMAX; j++) {
-                    if (j + 2 <= kt) {  // wave-uniform
-                        Pt[j + 2] = ra[j] * tc * Pt[j + 1] - rb[j] * Pt[j];
-                        Dt[j + 2] = Dt[j] + (2 * j + 3) * Pt[j + 1];
-                    } else {
-                        Pt[j + 2] = 0.;
-                        Dt[j + 2] = 0.;
-                    }
+                    Pt[j + 2] = ((double)(2 * j + 3) / (double)(j + 2)) * tc * Pt[j + 1] -
+                                ((double)(j + 1) / (double)(j + 2)) * Pt[j];
+                    Dt[j + 2] = Dt[j] + (2 * j + 3) * Pt[j + 1];
                 }
-                if (!tin) {
-#pragma unroll
-                    for (int j = 0; j <= KTMAX; j++) Dt[j] = 0.;
-                }
-            }
-            if constexpr (KTMAX >= 0) {
-                // two axial orders per trip: four independent accumulation chains
-                for (int i = 0; i <= ka; i += 2) {
-                    const bool two = i + 1 <= ka;
-                    const double Pz = pz0, dPz = zin ? dz0 : 0.;
-                    const double Pz1 = pz1, dPz1 = zin ? dz1 : 0.;
+                // two axial orders per trip: four independent accumulation chains; P'(t) = 0 outside
+                // [-1, 1] and P'(z) = 0 outside [-1, 1] enter the sums linearly -> applied once after the loop
+                for (int i = 0; i < rows; i += 2) {
                     double s0 = 0., s1 = 0., u0 = 0., u1 = 0.;
-                    const double *row0 = cm + i * (kt + 1), *row1 = two ? row0 + (kt + 1) : row0;
+                    const double *row0 = cmat + i * NT_, *row1 = row0 + NT_;   // kernel-argument segment: s_load
 #pragma unroll
                     for (int j = 0; j <= KTMAX; j++) {
-                        if (j <= kt) {
-                            const double c0 = row0[j], c1 = row1[j];
-                            s0 = __builtin_fma(c0, Pt[j], s0);   // tolerance-parity surface: FMA allowed here
-                            s1 = __builtin_fma(c0, Dt[j], s1);
-                            u0 = __builtin_fma(c1, Pt[j], u0);
-                            u1 = __builtin_fma(c1, Dt[j], u1);
-                        }
+                        const double c0 = row0[j], c1 = row1[j];
+                        s0 = __builtin_fma(c0, Pt[j], s0);   // tolerance-parity surface: FMA allowed here
+                        s1 = __builtin_fma(c0, Dt[j], s1);
+                        u0 = __builtin_fma(c1, Pt[j], u0);
+                        u1 = __builtin_fma(c1, Dt[j], u1);
                     }
-                    add += Pz * s0;
-                    addt += Pz * s1;
-                    addzz += dPz * s0;
-                    if (two) {
-                        add += Pz1 * u0;
-                        addt += Pz1 * u1;
-                        addzz += dPz1 * u0;
-                    }
+                    add += pz0 * s0;
+                    addt += pz0 * s1;
+                    addzz += dz0 * s0;
+                    add += pz1 * u0;
+                    addt += pz1 * u1;
+                    addzz += dz1 * u0;
                     // advance the z recurrences by two orders
-                    const double pn = ra[i] * zc * pz1 - rb[i] * pz0;
+                    const double pn = za[i] * zc * pz1 - zb[i] * pz0;
                     const double dn = dz0 + (2 * i + 3) * pz1;
-                    const double pn2 = ra[i + 1] * zc * pn - rb[i + 1] * pz1;
+                    const double pn2 = za[i + 1] * zc * pn - zb[i + 1] * pz1;
                     const double dn2 = dz1 + (2 * i + 5) * pn;
                     pz0 = pn;
                     pz1 = pn2;
                     dz0 = dn;
                     dz1 = dn2;
                 }
+                addt = tin ? addt : 0.;
+                addzz = zin ? addzz : 0.;
             } else {
+                const double *__restrict__ cm = lds();
+                const double *__restrict__ ra = cm + kLLMax, *__restrict__ rb = cm + 2 * kLLMax;
                 for (int i = 0; i <= ka; i++) {
                     const double Pz = pz0, dPz = zin ? dz0 : 0.;
                     double s0 = 0., s1 = 0.;  // sum_j C_ij P_j(t), sum_j C_ij P'_j(t)
@@ -633,6 +627,12 @@ static int fold_ll(LLData &op, double zmax, double zmin, double dphi, const doub
     for (int a = 0; a < cnum; a++) op.cmat[axial[a] * (kt + 1) + az[a]] += coeff[a];
     op.ka = ka;
     op.kt = kt;
+    op.rows = ka + 1;
+    op.stride = kt + 1;
+    for (int i = 0; i < kLLRows; i++) {
+        op.za[i] = (double)(2 * i + 3) / (double)(i + 2);
+        op.zb[i] = (double)(i + 1) / (double)(i + 2);
+    }
     op.zmid = (zmax + zmin) / 2.;
     op.zhalf = (zmax - zmin) / 2.;
     op.dphi = dphi;
@@ -658,26 +658,39 @@ static int conicplus_run(double *opd, double *x, double *y, double *z, const dou
     return launch_rays(c, num, mask, stream, op);
 }
 
+// Register form: repack the matrix to `cols` columns and an even number of rows (zero padding).
+// Returns false when it does not fit (then the generic LDS form runs).
+static bool ll_repack(LLData &d, int cols)
+{
+    const int rows = (d.ka + 2) & ~1;
+    if (d.kt + 1 > cols || rows > kLLRows || rows * cols > kLLMax) return false;
+    double m[kLLMax];
+    for (int i = 0; i < kLLMax; i++) m[i] = 0.;
+    for (int i = 0; i <= d.ka; i++)
+        for (int j = 0; j <= d.kt; j++) m[i * cols + j] = d.cmat[i * (d.kt + 1) + j];
+    for (int i = 0; i < kLLMax; i++) d.cmat[i] = m[i];
+    d.rows = rows;
+    d.stride = cols;
+    return true;
+}
+
 // launch with the smallest compile-time bound that covers the azimuthal orders present
 template <int KIND>
-static int ll_launch(const LLData &d, const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream)
+static int ll_launch(const LLData &d0, const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t stream)
 {
     static const bool force_generic = getenv("PXF_LL_GENERIC") != nullptr;   // dev knob (tools/bench_ops.py A/B)
-    if (!force_generic && d.kt <= 3) {
-        LLOp<KIND, 3> op{};
-        static_cast<LLData &>(op) = d;
-        return launch_rays(c, num, mask, stream, op);
+    LLData d = d0;
+#define PXF_LL_TRY(KT)                                       \
+    if (!force_generic && d.kt <= KT && ll_repack(d, KT + 1)) { \
+        LLOp<KIND, KT> op{};                                 \
+        static_cast<LLData &>(op) = d;                       \
+        return launch_rays(c, num, mask, stream, op);        \
     }
-    if (!force_generic && d.kt <= 7) {
-        LLOp<KIND, 7> op{};
-        static_cast<LLData &>(op) = d;
-        return launch_rays(c, num, mask, stream, op);
-    }
-    if (!force_generic && d.kt <= 15) {
-        LLOp<KIND, 15> op{};
-        static_cast<LLData &>(op) = d;
-        return launch_rays(c, num, mask, stream, op);
-    }
+    PXF_LL_TRY(3)
+    PXF_LL_TRY(7)
+    PXF_LL_TRY(11)
+    PXF_LL_TRY(15)
+#undef PXF_LL_TRY
     LLOp<KIND, -1> op{};
     static_cast<LLData &>(op) = d;
     return launch_rays(c, num, mask, stream, op);

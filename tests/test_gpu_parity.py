@@ -468,11 +468,17 @@ def test_special_values_bitwise(port, seed):
     assert n_checked >= 25
 
 
-@pytest.mark.parametrize("kt,ka", [(0, 0), (1, 6), (3, 3), (4, 2), (7, 7), (8, 10), (10, 10), (15, 15), (16, 5), (20, 11)])
+@pytest.mark.parametrize("kt,ka", [(0, 0), (1, 6), (3, 3), (3, 21), (4, 2), (7, 7), (8, 10), (10, 10),
+                                   (11, 19), (11, 20), (15, 15), (16, 5), (20, 11)])
 def test_legendre_legendre_order_ranges(port, kt, ka):
-    """The Legendre-Legendre kernels are instantiated for azimuthal orders <= 3, <= 7, <= 15 (register-
-    resident P_j) and for any order (regenerated recurrence): every variant against the oracle, with
-    dense random coefficient sets up to the given orders (10 x 10 is what the reference's examples fit)."""
+    """The Legendre-Legendre kernels are instantiated for azimuthal orders <= 3, <= 7, <= 11, <= 15 (register-
+    resident P_j, zero-padded matrix read through scalar loads; at most 32 padded axial rows and 256 cells) and
+    for any order (matrix in LDS, regenerated recurrence): every variant against the oracle, with dense random
+    coefficient sets up to the given orders (10 x 10 is what the reference's examples fit).  Orders stay <= 21:
+    the reference evaluates P_n by an explicit factorial sum (specialFunctions.f95:337-388) that loses digits
+    with n (5e-12 mm at order 20, 1e-10 at 30 for these amplitudes) and whose default-INTEGER `2**n` overflows
+    at n = 31 (sign flip; division by zero from 32 on) -- the kernels' three-term recurrences do neither, so
+    beyond ~order 25 the two part ways and it is the reference that is wrong (tools/dev/ll_debug.py)."""
     rng = np.random.default_rng(1000 * kt + ka)
     base = {name: (fn, cols, args) for name, fn, cols, args in cases.cases(num=300, seed=99)}
     nc = (ka + 1) * (kt + 1)
