@@ -345,6 +345,55 @@ def interpolateVec(rays, I, Nx, Ny, xr=None, yr=None, method='linear', polar=Fal
     return res, dx, dy
 
 
+def wavefront(rays, Nx, Ny, method='cubic', polar=False, maxiter=10000):
+    """Interpolate the beam slopes onto an Nx x Ny grid and integrate the wavefront (Southwell SOR on the
+    device, `native.reconstruct`); rays assumed in the xy plane (analyses.py:305-334).  Returns
+    (phase, xslope, yslope) as NumPy arrays with NaN where there are no rays.
+
+    PARITY UNPINNED -- the reference function cannot run as shipped: it calls
+    `reconstruct.reconstruct(y, x, 1e-12, dx, phase)` without the `maxiter` argument the Fortran requires
+    (reconstruct.f95:1-3; its own southwell.py passes it) and pads with `utilities.imaging.man.padRect`, which
+    is not vendored.  What it evidently intends is built from pinned pieces: `interpolateVec` (the reference's
+    own griddata call), a one-cell border of the reconstructor's NaN sentinel (the `[1:-1, 1:-1]` the
+    reference strips afterwards; `southwell.padArrays` does the same), criteria 1e-12, step dx, and
+    `native.reconstruct`, which is bit-identical to the compiled reconstruct.f95."""
+    from . import native
+    ys, dx, dy = interpolateVec(rays, 5, Nx, Ny, method=method, polar=polar)
+    xs, dx, dy = interpolateVec(rays, 4, Nx, Ny, method=method, polar=polar)
+    xs = np.pad(np.asarray(xs, dtype=np.float64), 1, constant_values=np.nan)
+    ys = np.pad(np.asarray(ys, dtype=np.float64), 1, constant_values=np.nan)
+    bad = np.isnan(xs) | np.isnan(ys)
+    phase = np.zeros(xs.shape)
+    phase[bad] = 100.
+    xs[bad] = 100.
+    ys[bad] = 100.
+    dev = rays[1].device
+    gx, gy, gp = native.fgrid(xs, dev), native.fgrid(ys, dev), native.fgrid(phase, dev)
+    out = native.reconstruct(gy, gx, 1e-12, float(dx), gp, int(maxiter)).cpu().numpy().copy()
+    out[out == 100] = np.nan
+    xs[xs == 100] = np.nan
+    ys[ys == 100] = np.nan
+    return out[1:-1, 1:-1], xs[1:-1, 1:-1], ys[1:-1, 1:-1]
+
+
+def measurePower(rays, Nx, Ny, method='linear'):
+    """Radius of curvature of the wavefront along x and y from the central slices of the interpolated
+    direction cosines; the sign equals the z transform that goes to focus (analyses.py:336-351).
+
+    PARITY UNPINNED -- the reference indexes with `Ny/2` / `Nx/2` (true division: a TypeError under Python 3)
+    and strips NaNs with the un-vendored `utilities.imaging.man.stripnans`; this is the same computation with
+    integer division and a plain NaN filter, on the reference's own `interpolateVec` grids."""
+    l, dx, dy = interpolateVec(rays, 4, Nx, Ny, method=method)
+    m = interpolateVec(rays, 5, Nx, Ny, method=method)[0]
+    xsl = l[Ny // 2]
+    ysl = m[:, Nx // 2]
+    xsl = xsl[~np.isnan(xsl)]
+    ysl = ysl[~np.isnan(ysl)]
+    xpow = 1 / np.gradient(xsl, dx)[min(Nx // 2, len(xsl) - 1)]
+    ypow = 1 / np.gradient(ysl, dy)[min(Ny // 2, len(ysl) - 1)]
+    return -xpow, -ypow
+
+
 def radialGrad(x, y, hubscale, yaw, hubdist):
     """x and y derivatives of a radial-grating phase function; hubscale = lambda / (nn/mm)
     (analyses.py:403-428, including its quirk: the yaw-rotated y2 is overwritten by y + hubdist).

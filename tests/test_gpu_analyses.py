@@ -120,3 +120,50 @@ def test_interpolateVec_equals_reference(golden):
     assert np.array_equal(anal.interpolateVec(rays, 5, 8, 8, polar=True)[0], g["blob/interp/polar"], equal_nan=True)
     got = anal.interpolateVec(rays, 0, 6, 6, xr=[0., 3.], yr=[-3., 1.], interpVec=rays[1] * rays[2])[0]
     assert np.array_equal(got, g["blob/interp/vec"], equal_nan=True)
+
+
+def test_wavefront_and_measurePower_converging_beam(port):
+    """analyses.wavefront / measurePower (analyses.py:305-351) -- parity UNPINNED: neither reference function
+    runs as shipped (missing `maxiter`, un-vendored `man.padRect` / `stripnans`, `Ny/2` indexing), so there is
+    no output to compare with.  Checked instead: (1) the pipeline equals the same steps taken by hand with
+    the reference's own griddata call and the ORACLE's reconstruct (= compiled reconstruct.f95), bit for bit;
+    (2) physics: a beam converging to a point R = 500 mm away has slopes l = -x/R, m = -y/R, so measurePower
+    returns (R, R) and the reconstructed phase is a paraboloid whose slope maps are the inputs."""
+    import pyxfocus_amd.analyses as anal
+    rng = np.random.default_rng(8)
+    n, R = 20000, 500.
+    x, y = rng.uniform(-10, 10, n), rng.uniform(-10, 10, n)
+    l, m = -x / R, -y / R
+    z = np.zeros(n)
+    cols = [z.copy(), x, y, z.copy(), l, m, -np.sqrt(1 - l * l - m * m), z.copy(), z.copy(), z + 1.]
+    rays = _dev(cols)
+    px, py = anal.measurePower(rays, 41, 41)
+    assert abs(px - R) < 1e-6 * R and abs(py - R) < 1e-6 * R, (px, py)
+    phase, xs, ys = anal.wavefront(rays, 33, 29, method='linear')
+    assert phase.shape == (29, 33) and xs.shape == phase.shape
+    # (1) by hand through the oracle
+    gy_, dx, dy = anal.interpolateVec(rays, 5, 33, 29, method='linear')
+    gx_ = anal.interpolateVec(rays, 4, 33, 29, method='linear')[0]
+    gx = np.pad(gx_, 1, constant_values=np.nan)
+    gy = np.pad(gy_, 1, constant_values=np.nan)
+    bad = np.isnan(gx) | np.isnan(gy)
+    ph = np.zeros(gx.shape, order='F')
+    ph[bad] = 100.
+    gx[bad] = 100.
+    gy[bad] = 100.
+    want = port.reconstruct.reconstruct(np.asfortranarray(gy), np.asfortranarray(gx), 1e-12, float(dx), ph, 10000)
+    want = np.array(want)
+    want[want == 100] = np.nan
+    assert np.array_equal(phase, want[1:-1, 1:-1], equal_nan=True)
+    assert np.array_equal(xs, gx_, equal_nan=True) and np.array_equal(ys, gy_, equal_nan=True)
+    # (2) the reconstructed phase reproduces the slope maps (central differences, interior nodes)
+    ok = ~np.isnan(phase)
+    assert ok.mean() > 0.8
+    d0 = (phase[2:, 1:-1] - phase[:-2, 1:-1]) / (2 * dx)       # along the first (row) axis
+    d1 = (phase[1:-1, 2:] - phase[1:-1, :-2]) / (2 * dx)
+    inner = ok[2:, 1:-1] & ok[:-2, 1:-1] & ok[1:-1, 2:] & ok[1:-1, :-2]
+    a, b = ys[1:-1, 1:-1], xs[1:-1, 1:-1]
+    scale = np.abs(a[inner]).max()
+    e_rows = min(np.abs(d0[inner] - s * a[inner]).max() for s in (1., -1.))
+    e_cols = min(np.abs(d1[inner] - s * b[inner]).max() for s in (1., -1.))
+    assert e_rows < 0.05 * scale and e_cols < 0.05 * scale, (e_rows, e_cols, scale)
