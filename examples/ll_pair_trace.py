@@ -13,6 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
 
+import pyxfocus_amd as pxf  # noqa: E402
 import pyxfocus_amd.analyses as anal  # noqa: E402
 import pyxfocus_amd.sources as sources  # noqa: E402
 import pyxfocus_amd.surfaces as surf  # noqa: E402
@@ -43,20 +44,25 @@ def pairRaytrace(secondaryTilt, despace, res, res2, num=10 ** 3, rays=None):
     ang = 260. / R0                                       # arc length over radius: the angular extent
     if rays is None:
         rays = sources.subannulus(R0, surf.con.primrad(ZP[1], R0, Z0), ang, num)
-    tran.transform(rays, 0, 0, 0, np.pi, 0, 0)            # point in -z ...
-    tran.transform(rays, 0, 0, -10000, 0, 0, 0)           # ... and converge from above
-
-    surf.primaryLL(rays, R0, Z0, ZP[1], ZP[0], ang, res[0], res[2], res[1])
+    # Each stretch between two vignettes is ONE launch (pyxfocus_amd.fused(): the Legendre-Legendre mirror runs
+    # inside the program with the frame changes and the reflection around it, bit-identical to separate calls)
+    with pxf.fused():
+        tran.transform(rays, 0, 0, 0, np.pi, 0, 0)            # point in -z ...
+        tran.transform(rays, 0, 0, -10000, 0, 0, 0)           # ... and converge from above
+        surf.primaryLL(rays, R0, Z0, ZP[1], ZP[0], ang, res[0], res[2], res[1])
     rays = _keep_between(rays, *ZP)
     numin = float(len(rays[1]))
-    tran.reflect(rays)
 
-    _about_secondary_midplane(rays, lambda r: tran.transform(r, 0, 0, despace, 0, secondaryTilt, 0))
-    surf.secondaryLL(rays, R0, Z0, 1., ZS[1], ZS[0], ang, res2[0], res2[2], res2[1])
+    with pxf.fused():
+        tran.reflect(rays)
+        _about_secondary_midplane(rays, lambda r: tran.transform(r, 0, 0, despace, 0, secondaryTilt, 0))
+        surf.secondaryLL(rays, R0, Z0, 1., ZS[1], ZS[0], ang, res2[0], res2[2], res2[1])
     rays = _keep_between(rays, *ZS)
     numout = float(len(rays[1]))
-    tran.reflect(rays)
-    _about_secondary_midplane(rays, lambda r: tran.itransform(r, 0, 0, despace, 0, secondaryTilt, 0))
+
+    with pxf.fused():
+        tran.reflect(rays)
+        _about_secondary_midplane(rays, lambda r: tran.itransform(r, 0, 0, despace, 0, secondaryTilt, 0))
 
     surf.focusI(rays)
     cx, cy = anal.centroid(rays)

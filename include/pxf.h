@@ -487,8 +487,22 @@ int pxf_source_ex(int32_t kind, double *const *cols, int64_t num, int64_t total,
 #define PXF_OP_TRACEZERNOPD 24 /* a: rad, nr  ; aux as above.  At most ONE Zernike operation per program, */
                                /* such a program holds at most PXF_PROGRAM_MAX_OPS_ZERN operations, unmasked, out of FLAT[OPD], */
                                /* [I]TRANSFORM, REFLECT (PXF_ERANGE otherwise: run the trace as its own launch) */
+/* Tolerance-parity MIRRORS inside a program (woltsurf.f95:167-215, 220-379, 387-588, 643-933): a program that
+ * holds any of them may hold at most PXF_PROGRAM_MAX_OPS_MIRROR operations, unmasked, out of these codes and
+ * FLAT[OPD], [I]TRANSFORM, REFLECT (PXF_ERANGE otherwise: run the mirror as its own launch); the Legendre-Legendre
+ * kinds take azimuthal orders <= 11, at most 15 axial orders each, and all their matrices -- zero-padded to a
+ * common multiple-of-four column count and an even row count -- must fit 288 cells (two 11 x 11 sets do). */
+#define PXF_OP_WSPRIMARY 26        /* a: alpha, z0, psi */
+#define PXF_OP_WSSECONDARY 27      /* a: alpha, z0, psi */
+#define PXF_OP_WSPRIMARYBACK 28    /* a: alpha, z0, psi, thick */
+#define PXF_OP_WSSECONDARYBACK 29  /* a: alpha, z0, psi, thick */
+#define PXF_OP_WOLTERSINE 30       /* a: r0, z0, amp, freq */
+#define PXF_OP_WOLTERPRIMLL 31     /* a: r0, z0, zmax, zmin, dphi       ; aux = (const double *)&pxf_ll_args_t on the HOST */
+#define PXF_OP_WOLTERSECLL 32      /* a: r0, z0, psi, zmax, zmin, dphi  ; aux as above */
+#define PXF_OP_ELLIPSOIDWOLTLL 33  /* a: r0, z0, psi, zmax, zmin, dphi  ; aux as above (its S field) */
 #define PXF_PROGRAM_MAX_OPS 32
 #define PXF_PROGRAM_MAX_OPS_ZERN 16
+#define PXF_PROGRAM_MAX_OPS_MIRROR 12
 #define PXF_PROGRAM_ZERN_MAX_ORDER 15 /* highest radial order of a FUSED Zernike trace (= of any Zernike trace) */
 
 /* host-side coefficient table of a PXF_OP_TRACEZERN[OPD] operation (the arguments of pxf_tracezern) */
@@ -498,6 +512,15 @@ typedef struct pxf_zern_args {
     const int32_t *aorder;
     int32_t arrsize;
 } pxf_zern_args_t;
+
+/* host-side coefficient list of a Legendre-Legendre operation (the trailing arguments of pxf_wolterprimll ...) */
+typedef struct pxf_ll_args {
+    const double *coeff;   /* HOST arrays of `cnum` entries */
+    const int32_t *axial;
+    const int32_t *az;
+    int32_t cnum;
+    double S;              /* PXF_OP_ELLIPSOIDWOLTLL only */
+} pxf_ll_args_t;
 
 typedef struct pxf_op {
     int32_t code;        /* PXF_OP_* */

@@ -8,7 +8,9 @@
     # <- here the rays are up to date
 
 Inside the block the per-ray calls (flat, conic, wolterprimary[opd], woltersecondary, transform,
-itransform, reflect, radgrat -- with or without ``ind``) are RECORDED instead of launched; at the
+itransform, reflect, radgrat -- with or without ``ind``; and, in programs of their own kind, a Zernike trace or
+the W-S / Legendre-Legendre / woltersine mirrors between frame changes, reflections and flats) are RECORDED
+instead of launched; at the
 end of the block (or at ``flush()``, or as soon as a call arrives that cannot be fused: vignette,
 applyT, pointTo, zernsurf, any analyses.* reduction, a call on a different bundle) the recorded
 program runs through ``pxf_program_run``: each column is read once and written once, with the ray in
@@ -40,7 +42,9 @@ OPCODES = {"pxf_flat": 1, "pxf_flatopd": 2, "pxf_conic": 3, "pxf_conicopd": 4, "
            "pxf_wolterprimaryopd": 6, "pxf_woltersecondary": 7, "pxf_transform": 8, "pxf_itransform": 9,
            "pxf_reflect": 10, "pxf_radgrat": 11, "pxf_radgratw": 12, "pxf_spocone": 13, "pxf_tracesphere": 14,
            "pxf_tracesphereopd": 15, "pxf_tracecyl": 16, "pxf_tracecylopd": 17, "pxf_cylconic": 18,
-           "pxf_paraxial": 19, "pxf_paraxialy": 20, "pxf_grat": 21, "pxf_refract": 22, "pxf_indangle": 25}
+           "pxf_paraxial": 19, "pxf_paraxialy": 20, "pxf_grat": 21, "pxf_refract": 22, "pxf_indangle": 25,
+           "pxf_wsprimary": 26, "pxf_wssecondary": 27, "pxf_wsprimaryback": 28, "pxf_wssecondaryback": 29,
+           "pxf_woltersine": 30}
 # bundle slots (opd=0, x=1 ... uz=9) of the columns each entry point takes, in call order
 SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5, 6, 7, 8, 9, 0),
          "pxf_conic": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_conicopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9),
@@ -52,19 +56,36 @@ SLOTS = {"pxf_flat": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_flatopd": (1, 2, 3, 4, 5,
          "pxf_tracesphereopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_tracecyl": (1, 2, 3, 4, 5, 6, 7, 8, 9),
          "pxf_tracecylopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_cylconic": (1, 2, 3, 4, 5, 6, 7, 8, 9),
          "pxf_paraxial": (1, 2, 4, 5), "pxf_paraxialy": (2, 5), "pxf_grat": (4, 5, 6, -1),
-         "pxf_refract": (4, 5, 6, 7, 8, 9), "pxf_indangle": (4, 5, 6, 7, 8, 9, -1)}
+         "pxf_refract": (4, 5, 6, 7, 8, 9), "pxf_indangle": (4, 5, 6, 7, 8, 9, -1),
+         "pxf_wsprimary": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_wssecondary": (1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_wsprimaryback": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_wssecondaryback": (1, 2, 3, 4, 5, 6, 7, 8, 9),
+         "pxf_woltersine": (1, 2, 3, 4, 5, 6, 7, 8, 9)}
 MAX_OPS = 32
 MAX_OPS_ZERN = 16      # PXF_PROGRAM_MAX_OPS_ZERN: a program around a Zernike trace
 ZERN_MAX_ORDER = 15    # PXF_PROGRAM_ZERN_MAX_ORDER
 # what a program around a Zernike trace may hold besides the trace (pxf_program_zern.hip: zprog_supported)
 ZERN_COMPANIONS = {1, 2, 8, 9, 10}     # flat, flatopd, transform, itransform, reflect
 ZERN_CODES = {"pxf_tracezern": 23, "pxf_tracezernopd": 24}
+# tolerance-parity mirrors inside a program (pxf_program_mirror.hip): W-S, woltersine (scalar arguments only) and
+# the Legendre-Legendre kinds (host coefficient lists).  Such a program holds at most 12 unmasked operations out of
+# the mirrors and flat, flatopd, transform, itransform, reflect; all L-L matrices share one 288-cell pool.
+MIRROR_SCALAR_CODES = {26, 27, 28, 29, 30}
+LL_CODES = {"pxf_wolterprimll": 31, "pxf_woltersecll": 32, "pxf_ellipsoidwoltll": 33}
+MIRROR_CODES = MIRROR_SCALAR_CODES | set(LL_CODES.values())
+MIRROR_COMPANIONS = {1, 2, 8, 9, 10}
+MAX_OPS_MIRROR = 12    # PXF_PROGRAM_MAX_OPS_MIRROR
+LL_POOL_CELLS, LL_POOL_ROWS, LL_MAX_AZ = 288, 16, 11
 ZERN_SLOTS = {"pxf_tracezern": (1, 2, 3, 4, 5, 6, 7, 8, 9), "pxf_tracezernopd": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)}
 
 
 class PxfZernArgs(C.Structure):
     _fields_ = [("coeff", C.POINTER(C.c_double)), ("rorder", C.POINTER(C.c_int32)), ("aorder", C.POINTER(C.c_int32)),
                 ("arrsize", C.c_int32)]
+
+
+class PxfLLArgs(C.Structure):
+    _fields_ = [("coeff", C.POINTER(C.c_double)), ("axial", C.POINTER(C.c_int32)), ("az", C.POINTER(C.c_int32)),
+                ("cnum", C.c_int32), ("S", C.c_double)]
 
 
 class PxfOp(C.Structure):
@@ -90,6 +111,8 @@ class _Recorder:
         self.ptrs = [0] * 10         # their device addresses (0 = slot not used yet)
         self.keep = []               # masks / aux columns / host tables kept alive until the launch
         self.has_zern = False        # the program holds its (one) Zernike operation
+        self.has_mirror = False      # the program holds W-S / Legendre-Legendre / woltersine mirrors
+        self.ll_shapes = []          # (highest axial order, highest azimuthal order) of its L-L operations
         self.num = None
         self.dev = None
 
@@ -123,6 +146,11 @@ class _Recorder:
             return False
         if self.has_zern and (mask is not None or OPCODES[name] not in ZERN_COMPANIONS):
             return False                              # no ind= masks / heavy operations around a Zernike trace
+        if OPCODES[name] in MIRROR_SCALAR_CODES and not self._mirror_may_join(mask):
+            return False
+        if self.has_mirror and (mask is not None or len(self.ops) >= MAX_OPS_MIRROR or
+                                OPCODES[name] not in (MIRROR_COMPANIONS | MIRROR_SCALAR_CODES)):
+            return False                              # ... nor around a W-S / L-L mirror
         ok, aux = self._bind(cols, SLOTS[name])
         if not ok:
             return False
@@ -134,12 +162,50 @@ class _Recorder:
             op.a[i] = float(v)
         self.ops.append(op)
         self.keep.extend(t for t in (mask, aux) if t is not None)
+        self.has_mirror |= op.code in MIRROR_SCALAR_CODES
+        return True
+
+    def _mirror_may_join(self, mask):
+        """A mirror operation can join the pending program: unmasked, no Zernike trace in it, every operation
+        recorded so far is one a mirror program may hold, and there is room."""
+        return (mask is None and not self.has_zern and len(self.ops) < MAX_OPS_MIRROR and
+                not any(o.mask or o.code not in (MIRROR_COMPANIONS | MIRROR_CODES) for o in self.ops))
+
+    def _ll_pool_fits(self, shapes):
+        if any(kt > LL_MAX_AZ or ((ka + 2) & ~1) > LL_POOL_ROWS for ka, kt in shapes):
+            return False
+        kt1 = max((kt + 4) & ~3 for _, kt in shapes)
+        return sum(((ka + 2) & ~1) * kt1 for ka, _ in shapes) <= LL_POOL_CELLS
+
+    def try_add_ll(self, name, cols, scalars, tables, S, mask):
+        """Record a Legendre-Legendre mirror.  `tables` = ((coeff, axial, az) host arrays, their ctypes pointers +
+        length); all L-L matrices of a program share one zero-padded pool (module constants above)."""
+        (ck, ak, zk), (cp, ap, zp, n) = tables
+        if not self._mirror_may_join(mask) or n == 0:
+            return False
+        shape = (int(ak.max()), int(zk.max()))
+        if not self._ll_pool_fits(self.ll_shapes + [shape]):
+            return False
+        ok, _ = self._bind(cols, (1, 2, 3, 4, 5, 6, 7, 8, 9))
+        if not ok:
+            return False
+        la = PxfLLArgs(cp, ap, zp, n, float(S))
+        op = PxfOp()
+        op.code = LL_CODES[name]
+        op.mask = None
+        op.aux = C.addressof(la)
+        for i, v in enumerate(scalars):
+            op.a[i] = float(v)
+        self.ops.append(op)
+        self.keep.extend((la, ck, ak, zk))
+        self.ll_shapes.append(shape)
+        self.has_mirror = True
         return True
 
     def try_add_zern(self, name, cols, tables, rad, nr, mask):
         """Record a tracezern[opd] call.  `tables` = (coeff, rorder, aorder) host arrays and their ctypes
         pointers; one Zernike operation per program, and such a program holds at most 16 operations."""
-        if self.has_zern or len(self.ops) >= MAX_OPS_ZERN or mask is not None:
+        if self.has_zern or self.has_mirror or len(self.ops) >= MAX_OPS_ZERN or mask is not None:
             return False
         if any(o.mask or o.code not in ZERN_COMPANIONS for o in self.ops):
             return False

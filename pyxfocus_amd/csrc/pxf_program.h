@@ -26,7 +26,7 @@ struct Program {
 static_assert(sizeof(Program) + sizeof(Cols) + 64 <= 4096, "program must fit the kernel-argument segment");
 
 // One-hot image of an op code (codes 1..28) above the three transform-group bits of ProgOp::flags.
-__host__ __device__ constexpr int prog_onehot(int code) { return 1 << (2 + code); }
+__host__ __device__ constexpr int prog_onehot(int code) { return code <= PXF_OP_INDANGLE ? 1 << (2 + code) : 0; }
 static_assert(PXF_OP_INDANGLE + 2 < 31, "op codes must fit the one-hot field of ProgOp::flags");
 
 template <class OP, int V>
@@ -138,11 +138,18 @@ __device__ __forceinline__ void exec_op(int code, int flags, const double *__res
 
 // host planner (pxf_program.hip): micro-ops, liveness, load / store sets; `zern_op` receives the index
 // (after dead-op compaction) of the program's Zernike operation, or -1
-int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, int *zern_op = nullptr);
+// `has_mirror`: the program holds a tolerance-parity mirror (PXF_OP_WSPRIMARY .. PXF_OP_ELLIPSOIDWOLTLL); plan_program
+// returns PXF_ERANGE for such a program if the caller did not ask (segmented / tolerance-mode programs cannot hold one)
+int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, int *zern_op = nullptr,
+                 bool *has_mirror = nullptr);
 
 // pxf_program_zern.hip: launch a planned program whose operation `iz` is a Zernike trace
 // (PXF_OP_TRACEZERN[OPD]); `za` is the host-side table of that operation
 int launch_program_zern(const Program &pg, int iz, const pxf_zern_args_t *za, const Cols &c, int64_t num,
                         pxf_stream_t stream);
+
+// pxf_program_mirror.hip: launch a planned program that holds mirror operations (their p[0..5] = the caller's
+// scalars, aux = the host pxf_ll_args_t of a Legendre-Legendre kind)
+int launch_program_mirror(const Program &pg, const Cols &c, int64_t num, pxf_stream_t stream);
 
 }  // namespace pxf

@@ -167,9 +167,10 @@ struct Micro {
     bool side;            // writes outside the bundle (an output column): never dead
 };
 
-int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, int *zern_op)
+int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, int *zern_op, bool *has_mirror)
 {
     int zern_src = -1;  // index (in the caller's list) of the Zernike operation, if any
+    bool mirror = false;
     if (nops < 0 || nops > kMaxOps || (nops > 0 && !ops)) return PXF_EINVAL;
     Micro mi[kMaxOps * 3];
     int nm = 0;
@@ -309,9 +310,29 @@ int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, i
                 add(POS | DIR | (wopd ? B(OPD) : 0u), POS | NRM | (wopd ? B(OPD) : 0u), 0, 0);
                 break;
             }
+            case PXF_OP_WOLTERPRIMLL:
+            case PXF_OP_WOLTERSECLL:
+            case PXF_OP_ELLIPSOIDWOLTLL:
+                if (!u.aux) return PXF_EINVAL;  // needs its host coefficient list
+                // fallthrough
+            case PXF_OP_WOLTERSINE:
+                mirror = true;
+                for (int k = 0; k < 6; k++) o.p[k] = u.a[k];   // derived constants: launch_program_mirror
+                add(POS | DIR, POS | NRM, 0, 0);
+                break;
+            case PXF_OP_WSPRIMARY:
+            case PXF_OP_WSSECONDARY:
+            case PXF_OP_WSPRIMARYBACK:
+            case PXF_OP_WSSECONDARYBACK:
+                mirror = true;
+                for (int k = 0; k < 6; k++) o.p[k] = u.a[k];
+                add(POS | DIR, POS, NRM, 0);   // 26 steps without convergence: position restored, normal kept
+                break;
             default: return PXF_EINVAL;
         }
     }
+    if (mirror && (!has_mirror || zern_src >= 0)) return PXF_ERANGE;
+    if (has_mirror) *has_mirror = mirror;
     // backward liveness: every column is observable when the program ends
     unsigned live = 0x3ffu;
     int dead = 0;
@@ -348,6 +369,7 @@ int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, i
     for (int i = 0; i < k; i++) pg.op[i].flags |= prog_onehot(pg.op[i].code);
     if (zern_op) *zern_op = zk;
     if (zk >= 0 && k > PXF_PROGRAM_MAX_OPS_ZERN) return PXF_ERANGE;
+    if (mirror && k > PXF_PROGRAM_MAX_OPS_MIRROR) return PXF_ERANGE;
     pg.load = load;
     pg.store = store;
     if (dropped) *dropped = dead;
@@ -365,7 +387,8 @@ int pxf_program_plan(const pxf_op_t *ops, int32_t nops, uint32_t *load_mask, uin
 {
     Program pg{};
     int dead = 0;
-    int rc = plan_program(ops, nops, pg, &dead);
+    bool mirror = false;
+    int rc = plan_program(ops, nops, pg, &dead, nullptr, &mirror);
     if (rc != PXF_OK) return rc;
     if (load_mask) *load_mask = pg.load;
     if (store_mask) *store_mask = pg.store;
@@ -377,10 +400,19 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
 {
     Program pg{};
     int iz = -1;
-    int rc = plan_program(ops, nops, pg, nullptr, &iz);
+    bool mirror = false;
+    int rc = plan_program(ops, nops, pg, nullptr, &iz, &mirror);
     if (rc != PXF_OK) return rc;
     if (num < 0 || !cols) return PXF_EINVAL;
     if (num == 0 || pg.nops == 0) return PXF_OK;
+    if (mirror) {  // a program that holds W-S / Legendre-Legendre / woltersine mirrors: its own kernel
+        Cols cm{};
+        for (int col = 0; col < 10; col++) {
+            cm.p[col] = cols[col];
+            if (((pg.load | pg.store) & B(col)) && !cols[col]) return PXF_EINVAL;
+        }
+        return launch_program_mirror(pg, cm, num, stream);
+    }
     if (iz >= 0) {  // a program around a Zernike trace: its own kernel (one ray per thread, LDS table)
         Cols cz{};
         for (int col = 0; col < 10; col++) {

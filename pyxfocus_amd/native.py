@@ -221,7 +221,6 @@ def woltersecondary(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, mask=None):
 
 
 def woltersine(x, y, z, l, m, n, ux, uy, uz, r0, z0, amp, freq, mask=None):
-    fused.flush()
     _call("pxf_woltersine", (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (r0, z0, amp, freq)), mask)
 
 
@@ -235,44 +234,62 @@ def _ll_tables(coeff, axial, az):
     return (ck, ak, zk), (ck.ctypes.data_as(_lib._DP), ak.ctypes.data_as(_lib._IP), zk.ctypes.data_as(_lib._IP), len(ck))
 
 
+def _record_ll(name, cols, scalars, tables, S, mask):
+    """Inside a fused() block: record the Legendre-Legendre mirror into the pending program (True), making room
+    for it by flushing if need be; False = run it as a stand-alone launch."""
+    rec = fused.active()
+    if rec is None:
+        return False
+    num, dev = _check_cols(cols, name)
+    _mask_ptr(mask, num, dev, name)
+    if num == 0:
+        return True
+    if rec.try_add_ll(name, cols, scalars, tables, S, mask):
+        return True
+    rec.flush()
+    return rec.try_add_ll(name, cols, scalars, tables, S, mask)
+
+
 def wolterprimll(x, y, z, l, m, n, ux, uy, uz, r0, z0, zmax, zmin, dphi, coeff, axial, az, mask=None):
-    keep, t = _ll_tables(coeff, axial, az)
+    tables = _ll_tables(coeff, axial, az)
+    cols, sc = (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (r0, z0, zmax, zmin, dphi))
+    if _record_ll("pxf_wolterprimll", cols, sc, tables, 0., mask):
+        return
     fused.flush()
-    _call("pxf_wolterprimll", (x, y, z, l, m, n, ux, uy, uz),
-          tuple(float(v) for v in (r0, z0, zmax, zmin, dphi)) + t, mask)
+    _call("pxf_wolterprimll", cols, sc + tables[1], mask)
 
 
 def woltersecll(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, zmax, zmin, dphi, coeff, axial, az, mask=None):
-    keep, t = _ll_tables(coeff, axial, az)
+    tables = _ll_tables(coeff, axial, az)
+    cols, sc = (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (r0, z0, psi, zmax, zmin, dphi))
+    if _record_ll("pxf_woltersecll", cols, sc, tables, 0., mask):
+        return
     fused.flush()
-    _call("pxf_woltersecll", (x, y, z, l, m, n, ux, uy, uz),
-          tuple(float(v) for v in (r0, z0, psi, zmax, zmin, dphi)) + t, mask)
+    _call("pxf_woltersecll", cols, sc + tables[1], mask)
 
 
 def ellipsoidwoltll(x, y, z, l, m, n, ux, uy, uz, r0, z0, psi, S, zmax, zmin, dphi, coeff, axial, az, mask=None):
-    keep, t = _ll_tables(coeff, axial, az)
+    tables = _ll_tables(coeff, axial, az)
+    cols = (x, y, z, l, m, n, ux, uy, uz)
+    if _record_ll("pxf_ellipsoidwoltll", cols, tuple(float(v) for v in (r0, z0, psi, zmax, zmin, dphi)), tables, S, mask):
+        return
     fused.flush()
-    _call("pxf_ellipsoidwoltll", (x, y, z, l, m, n, ux, uy, uz),
-          tuple(float(v) for v in (r0, z0, psi, S, zmax, zmin, dphi)) + t, mask)
+    _call("pxf_ellipsoidwoltll", cols, tuple(float(v) for v in (r0, z0, psi, S, zmax, zmin, dphi)) + tables[1], mask)
 
 
 def wsprimary(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, mask=None):
-    fused.flush()
     _call("pxf_wsprimary", (x, y, z, l, m, n, ux, uy, uz), (float(alpha), float(z0), float(psi)), mask)
 
 
 def wssecondary(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, mask=None):
-    fused.flush()
     _call("pxf_wssecondary", (x, y, z, l, m, n, ux, uy, uz), (float(alpha), float(z0), float(psi)), mask)
 
 
 def wsprimaryback(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, thick, mask=None):
-    fused.flush()
     _call("pxf_wsprimaryback", (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (alpha, z0, psi, thick)), mask)
 
 
 def wssecondaryback(x, y, z, l, m, n, ux, uy, uz, alpha, z0, psi, thick, mask=None):
-    fused.flush()
     _call("pxf_wssecondaryback", (x, y, z, l, m, n, ux, uy, uz), tuple(float(v) for v in (alpha, z0, psi, thick)), mask)
 
 

@@ -7,6 +7,7 @@ total focus shift, like the reference).
 import numpy as np
 
 from . import analyses
+from . import _fused
 from . import conicsolve as con
 from . import transformations as tran
 from .native import surfacesf as surf
@@ -272,9 +273,11 @@ def _ws(fn, rays, r0, z0, psi, check):
     opd, x, y, z, l, m, n, ux, uy, uz = rays
     a, p, d, e = con.woltparam(r0, z0)
     if check is True:
+        _fused.flush()           # (inside a fused() block: the positions must be current before and after)
         x0, y0, zz0 = x.clone(), y.clone(), z.clone()
     fn(x, y, z, l, m, n, ux, uy, uz, a, z0, psi)
     if check is True:
+        _fused.flush()
         return (x0 == x) & (y0 == y) & (zz0 == z)
     return
 

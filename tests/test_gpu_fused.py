@@ -541,3 +541,142 @@ def test_fast_program_falls_back_and_covers_every_supported_op(port):
             assert np.abs(got[k][f] - want[k][f]).max() <= tol, (name, k, np.abs(got[k][f] - want[k][f]).max())
         checked += 1
     assert checked >= 8
+
+
+MIRRORS = ("woltersine", "wolterprimll", "woltersecll", "ellipsoidwoltll", "wsprimary", "wssecondary",
+           "wsprimaryback", "wssecondaryback")
+
+
+def _mirror_cases(num, seed):
+    return {name: (fn, cols, args) for name, fn, cols, args in cases.cases(num=num, seed=seed) if name in MIRRORS}
+
+
+@pytest.mark.parametrize("n", [64, 777, 60_001])
+def test_fused_program_around_mirrors(n):
+    """W-S / Legendre-Legendre / woltersine mirrors INSIDE a program (pxf_program_mirror.hip): small frame
+    change -> mirror -> reflect -> frame change back -> flat as ONE launch, bit-identical to the five
+    stand-alone launches (the mirror Ops are the same device code: WSOp::apply, ll_trace, WolterSineOp::apply),
+    failed W-S rays (position restored, normal kept) included."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    for name, (fn, cols, args) in _mirror_cases(n, 17).items():
+        def chain(t):
+            rays = [t[k] for k in ALLCOLS]
+            tran.transform(rays, 1e-3, -2e-3, 0., 1e-6, -1e-6, 0.)
+            call_gpu(fn, t, args)
+            tran.reflect(rays)
+            tran.itransform(rays, 1e-3, -2e-3, 0., 1e-6, -1e-6, 0.)
+            surf.flat(rays)
+        a, b = to_dev(cols), to_dev(cols)
+        chain(a)
+        with pxf.fused() as rec:
+            chain(b)
+        assert rec.launches == 1 and rec.fused_ops == 5, (name, rec.launches, rec.fused_ops)
+        for k in ALLCOLS:
+            assert bits_equal(a[k].cpu().numpy(), b[k].cpu().numpy()).all(), (name, k)
+
+
+def test_fused_mirror_pairs_limits_and_fallbacks():
+    """Two mirrors in one program (a W-S pair; two 11 x 11 Legendre-Legendre sets sharing the coefficient pool),
+    and everything the mirror program does not take -- `ind=` masks, a 13th operation, matrices that overflow
+    the pool, azimuthal orders > 11, a Zernike trace next to a mirror, check=True -- falls back to separate
+    launches with the same bits."""
+    import pyxfocus_amd as pxf
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    from pyxfocus_amd import native
+    mc = _mirror_cases(4001, 23)
+    rng = np.random.default_rng(5)
+
+    def both(cols, chain, launches, ops=None):
+        a, b = to_dev(cols), to_dev(cols)
+        chain(a, [a[k] for k in ALLCOLS])
+        with pxf.fused() as rec:
+            chain(b, [b[k] for k in ALLCOLS])
+        assert rec.launches == launches and (ops is None or rec.fused_ops == ops), (rec.launches, rec.fused_ops)
+        for k in ALLCOLS:
+            assert bits_equal(a[k].cpu().numpy(), b[k].cpu().numpy()).all(), k
+
+    # W-S pair: primary -> reflect -> secondary -> reflect -> flat
+    fn1, cols, a1 = mc["wsprimary"]
+    fn2, _, a2 = mc["wssecondary"]
+
+    def ws_pair(t, rays):
+        call_gpu(fn1, t, a1)
+        tran.reflect(rays)
+        call_gpu(fn2, t, a2)
+        tran.reflect(rays)
+        surf.flat(rays)
+    both(cols, ws_pair, 1, 5)
+
+    # L-L pair with 11 x 11 coefficient sets (what the reference's examples fit): one pool, one launch
+    fnp, cols, ap = mc["wolterprimll"]
+    fns, _, as_ = mc["woltersecll"]
+
+    def ll_set(ka, kt, seed):
+        r = np.random.default_rng(seed)
+        ax, az = np.meshgrid(np.arange(ka + 1), np.arange(kt + 1), indexing="ij")
+        co = r.normal(0., 2e-5, ax.size) / (1 + ax.flatten() + az.flatten())
+        return co, ax.flatten().astype(np.int32), az.flatten().astype(np.int32)
+
+    def ll_pair(sets):
+        def chain(t, rays):
+            call_gpu(fnp, t, tuple(ap[:-3]) + sets[0])
+            tran.reflect(rays)
+            tran.transform(rays, 0, 0, 1e-2, 0, 1e-6, 0)
+            call_gpu(fns, t, tuple(as_[:-3]) + sets[1])
+            tran.reflect(rays)
+        return chain
+    both(cols, ll_pair((ll_set(10, 10, 1), ll_set(10, 10, 2))), 1, 5)
+    both(cols, ll_pair((ll_set(3, 2, 1), ll_set(14, 7, 2))), 1, 5)          # mixed shapes: common column count 8
+    both(cols, ll_pair((ll_set(13, 11, 1), ll_set(13, 11, 2))), 2)          # 2 x 14 x 12 cells > pool: two programs
+    both(cols, ll_pair((ll_set(4, 12, 1), ll_set(3, 3, 2))), 1, 4)          # azimuthal order 12: that mirror runs stand-alone
+
+    # an ind= mask on the mirror, a 13th operation, a conic in between: separate launches, same bits
+    fn, cols, args = mc["wsprimary"]
+    msk = torch.from_numpy(rng.random(len(cols["x"])) < .5).cuda()
+
+    def masked(t, rays):
+        tran.transform(rays, 0, 0, 1e-3, 0, 0, 0)
+        call_gpu(fn, t, args, mask=msk.to(torch.uint8))
+        tran.reflect(rays)
+    both(cols, masked, 2)
+
+    def long_chain(t, rays):
+        for _ in range(6):
+            tran.transform(rays, 0, 0, 1e-3, 0, 0, 0)
+            tran.itransform(rays, 0, 0, 1e-3, 0, 0, 0)
+        call_gpu(fn, t, args)
+    both(cols, long_chain, 2, 13)
+
+    def with_conic(t, rays):
+        call_gpu(fn, t, args)
+        tran.reflect(rays)
+        surf.conic(rays, -500., -1.)
+        tran.reflect(rays)
+    both(cols, with_conic, 2, 4)
+
+    # a Zernike trace and a mirror never share a program
+    ro, ao = cases.noll_orders(10)
+    zc = rng.normal(0, 1e-4, 10)
+
+    def with_zern(t, rays):
+        call_gpu(fn, t, args)
+        tran.reflect(rays)
+        surf.zernsurf(rays, zc, 2000., rorder=ro, aorder=ao)
+    both(cols, with_zern, 2, 3)
+
+    # check=True reads the positions back: flushes before and after
+    a = to_dev(cols)
+    ra = [a[k] for k in ALLCOLS]
+    tran.transform(ra, 0, 0, 1e-3, 0, 0, 0)
+    want = surf.wsPrimary(ra, cases.R0, cases.Z0, cases.PSI, check=True)
+    b = to_dev(cols)
+    rb = [b[k] for k in ALLCOLS]
+    with pxf.fused():
+        tran.transform(rb, 0, 0, 1e-3, 0, 0, 0)
+        got = surf.wsPrimary(rb, cases.R0, cases.Z0, cases.PSI, check=True)
+    assert torch.equal(want, got)
+    for k in ALLCOLS:
+        assert bits_equal(a[k].cpu().numpy(), b[k].cpu().numpy()).all(), k

@@ -94,6 +94,28 @@ def main():
     a17, z17 = np.meshgrid(np.arange(6), np.arange(17), indexing="ij")
     ll17c, ll17a, ll17z = rng.normal(0, 1e-5, 102) / (1 + a17.flatten() + z17.flatten()), a17.flatten(), z17.flatten()
 
+    import contextlib
+    import pyxfocus_amd as pxf
+
+    def ll_pair(r, fuse):
+        with (pxf.fused() if fuse else contextlib.nullcontext()):
+            surf.primaryLL(r, R0, Z0, Z0 + L, Z0, 2 * np.pi, ll11c, ll11a, ll11z)
+            tran.reflect(r)
+            tran.transform(r, 0, 0, 1e-3, 0, 1e-6, 0)
+            surf.secondaryLL(r, R0, Z0, PSI, Z0, Z0 - L, 2 * np.pi, ll11c, ll11a, ll11z)
+            tran.reflect(r)
+            tran.itransform(r, 0, 0, 1e-3, 0, 1e-6, 0)
+            surf.flat(r)
+
+    def ws_pair(r, fuse):
+        with (pxf.fused() if fuse else contextlib.nullcontext()):
+            surf.wsPrimary(r, R0, Z0, PSI)
+            tran.reflect(r)
+            surf.wsSecondary(r, R0, Z0, PSI)
+            tran.reflect(r)
+            tran.transform(r, 0, 0, -1e-3, 0, 0, 0)
+            surf.flat(r)
+
     ops = [
         # name, input builder, call, algorithmic B/ray
         ("transform", wolter_in, lambda r: tran.transform(r, .1, -.2, 3., 1e-3, -2e-3, .5), 144),
@@ -115,6 +137,12 @@ def main():
          lambda r: surf.primaryLL(r, R0, Z0, Z0 + L, Z0, 2 * np.pi, ll17c, ll17a, ll17z), 96),
         ("secondaryLL", secondary_in,
          lambda r: surf.secondaryLL(r, R0, Z0, PSI, Z0, Z0 - L, 2 * np.pi, llc, lla, llz), 96),
+        # a mirror PAIR with the frame changes and reflections around it: one launch per call vs ONE launch
+        # (pyxfocus_amd.fused(): pxf_program_mirror.hip); algorithmic bytes of the one-launch form
+        ("LL pair 11x11, per call (7 launches)", wolter_in, lambda r: ll_pair(r, False), 120),
+        ("LL pair 11x11, fused (1 launch)", wolter_in, lambda r: ll_pair(r, True), 120),
+        ("W-S pair, per call (6 launches)", wolter_in, lambda r: ws_pair(r, False), 120),
+        ("W-S pair, fused (1 launch)", wolter_in, lambda r: ws_pair(r, True), 120),
         ("wsPrimary", wolter_in, lambda r: surf.wsPrimary(r, R0, Z0, PSI), 96),
         ("wsPrimaryB", wolter_in, lambda r: surf.wsPrimaryB(r, R0, Z0, PSI, .4), 96),
         ("wsSecondary", ws_secondary_in, lambda r: surf.wsSecondary(r, R0, Z0, PSI), 96),
