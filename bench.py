@@ -6,7 +6,9 @@ r0=220, z0=8400, psi=1, L=100, fp64; one STEP = the reference call chain, one HI
 PyXFocus API call (the drop-in contract):
 
     tran.transform(rays,0,0,-(z0+2L),0,0,0) -> surf.wolterprimary -> tran.reflect
-        -> surf.woltersecondary -> tran.reflect -> surf.flat            (576 algorithmic B/ray)
+        -> surf.woltersecondary -> tran.reflect -> surf.flat            (512 algorithmic B/ray: SURVEY 8(d)'s 576
+                                                                         less the 64 B the leading pure translation
+                                                                         does not rewrite, tools/workloads.py)
 
 Every step traces a FRESH bundle (the chain mutates rays in place, so re-tracing a traced bundle
 would be different work): K+W bundles are generated on the device before the timed region
@@ -231,7 +233,7 @@ def parity_vs_checker(chain_np, chain_dev, make_cols, dev, tol_note):
 
 
 def bench_config3(n, steps, dev, pxf, sources, tran, surf, con):
-    """BASELINE config 3: config-2 chain + one radial grating stage, 12 launches, 1192 B/ray."""
+    """BASELINE config 3: config-2 chain + one radial grating stage, 12 launches, 1128 B/ray."""
     rin, rout = float(con.primrad(Z0, R0, Z0)), float(con.primrad(Z0 + LMIR, R0, Z0))
     fresh = lambda seed: sources.subannulus(rin, rout, 0.5, n, zhat=-1., rng="philox", seed=seed)
     per, fms = [], []
@@ -635,7 +637,7 @@ def main():
                 "traffic_source": ("%s @ %s (csrc %s)" % (tr["source"], tr["commit"], csrc_hash())) if tr else
                 "none for the kernel sources of this build (csrc %s): run tools/pmc_collect.py" % csrc_hash(),
                 "algorithmic_bytes_per_launch": dom["bytes_per_ray"] * N, "avg_launch_ms": dom["avg_ms"]}
-    chain_gbps = 576.0 * N / (sum(k["avg_ms"] for k in kern) * 1e-3) / 1e9
+    chain_gbps = float(wl.BYTES["config2"]) * N / (sum(k["avg_ms"] for k in kern) * 1e-3) / 1e9
     # measured device-to-device copy of the same nine columns ("also report against a
     # measured copy kernel") -- what a 9R+9W stream reaches on this GPU with no arithmetic at all
     try:
@@ -659,7 +661,7 @@ def main():
         pass
 
     # ---- the same K steps again as ONE fused launch per step (reported separately, never mixed
-    # into `value`: 120 algorithmic B/ray instead of 576; bit-identical results) --------------------
+    # into `value`: 120 algorithmic B/ray instead of 512; bit-identical results) --------------------
     last = bundles[(K - 1) % pool]
     del bundles                      # keep only the last traced bundle (focal-plane metrics below)
     torch.cuda.empty_cache()
@@ -772,7 +774,10 @@ def main():
                "config": {"workload": "config2: %g rays/GPU annulus -> transform -> wolterprimary -> reflect -> "
                                       "woltersecondary -> reflect -> flat; r0=220 z0=8400 psi=1 L=100; one HIP "
                                       "launch per PyXFocus call" % N,
-                          "rays_per_gpu": N, "launches_per_step": 6, "algorithmic_bytes_per_ray": 576,
+                          "rays_per_gpu": N, "launches_per_step": 6, "algorithmic_bytes_per_ray": wl.BYTES["config2"],
+                          "algorithmic_bytes_note": "SURVEY 8(d) books 576 with every transform at 144 B; the leading pure "
+                                                    "translation is read whole (72 B) and only its changed column z is "
+                                                    "rewritten (8 B): 80 B, confirmed by the PMC traffic",
                           "parallelism": "ray-sharded x%d, no data-path collective" % n_gpus,
                           "world_size": dist.get_world_size() if dist else 1,
                           "backend": (args.backend if dist else None), "devices": ndev,

@@ -94,7 +94,7 @@ def main():
             med, mn = float(np.median(t)), float(t.min())
             tot_med += med
             parts.append("%s %.3f/%.3f (%.0f)" % (k[:8], med, mn, b * N / (med * 1e-3) / 1e9))
-        print("%-10s chain %.3f ms  %.0f GB/s | %s" % (name, tot_med, 576 * N / (tot_med * 1e-3) / 1e9, " | ".join(parts)))
+        print("%-10s chain %.3f ms  %.0f GB/s | %s" % (name, tot_med, 512 * N / (tot_med * 1e-3) / 1e9, " | ".join(parts)))
     shutil.rmtree(tmp, ignore_errors=True)
 
 
