@@ -139,10 +139,10 @@ def main():
          lambda r: surf.secondaryLL(r, R0, Z0, PSI, Z0, Z0 - L, 2 * np.pi, llc, lla, llz), 96),
         # a mirror PAIR with the frame changes and reflections around it: one launch per call vs ONE launch
         # (pyxfocus_amd.fused(): pxf_program_mirror.hip); algorithmic bytes of the one-launch form
-        ("LL pair 11x11, per call (7 launches)", wolter_in, lambda r: ll_pair(r, False), 120),
-        ("LL pair 11x11, fused (1 launch)", wolter_in, lambda r: ll_pair(r, True), 120),
-        ("W-S pair, per call (6 launches)", wolter_in, lambda r: ws_pair(r, False), 120),
-        ("W-S pair, fused (1 launch)", wolter_in, lambda r: ws_pair(r, True), 120),
+        ("LL pair 11x11 per call (7 launches)", wolter_in, lambda r: ll_pair(r, False), 120),
+        ("LL pair 11x11 fused (1 launch)", wolter_in, lambda r: ll_pair(r, True), 120),
+        ("W-S pair per call (6 launches)", wolter_in, lambda r: ws_pair(r, False), 120),
+        ("W-S pair fused (1 launch)", wolter_in, lambda r: ws_pair(r, True), 120),
         ("wsPrimary", wolter_in, lambda r: surf.wsPrimary(r, R0, Z0, PSI), 96),
         ("wsPrimaryB", wolter_in, lambda r: surf.wsPrimaryB(r, R0, Z0, PSI, .4), 96),
         ("wsSecondary", ws_secondary_in, lambda r: surf.wsSecondary(r, R0, Z0, PSI), 96),

@@ -172,14 +172,17 @@ def write_tables(tag, target, ks, rays, note, launch_bytes):
     base = os.path.join(OUTDIR, "%s_%s_kernels" % (tag, target))
     json.dump({"tag": tag, "target": target, "rays_per_launch": rays, "note": note, "kernels": ks}, open(base + ".json", "w"),
               indent=1)
-    alg = {}
-    for lname, nb in launch_bytes:
-        for op in ks:
-            if LAUNCH_KERNEL.get(lname) == op:
-                alg[op] = nb
+    alg, per_op = {}, defaultdict(list)
+    for lname, nb in launch_bytes:                  # a kernel launched several times per chain with different write
+        per_op[LAUNCH_KERNEL.get(lname)].append(nb)  # sets (transform: pure translation 80 B, rotation 144 B): the
+    for op in ks:                                   # trace averages over them, so does the algorithmic figure
+        if per_op.get(op):
+            alg[op] = sum(per_op[op]) / len(per_op[op])
     for op in ks:                                   # surface intersections: 6 columns in, 6 out
         if op.split("<")[0] in ("LLOp", "WSOp", "WolterSineOp", "ZernOpSel", "WolterPrimaryOp", "WolterSecondaryOp"):
             alg.setdefault(op, 96)
+        if op.split("<")[0] == "program_mirror_kernel":
+            alg.setdefault(op, 120)                 # a mirror pair with its frame changes: 6 columns in, 9 out
         if op.split("<")[0] in ("program_kernel", "program_zern_kernel", "program_fast_kernel") and target not in ("ops", "config5"):
             alg.setdefault(op, 120)                 # the configs' programs: 6 columns in, 9 out
         if op.split("<")[0] in ("program_seg_kernel", "program_fast_seg_kernel"):
@@ -200,7 +203,7 @@ def write_tables(tag, target, ks, rays, note, launch_bytes):
         hb = e.get("hbm_bytes_per_launch")
         fl = e.get("fp64_flops_per_launch")
         lines.append("| `%s` | %d | %.3f | %s | %s | %s | %s | %s | %s | %s | %s | %s | %d | %d | %d | %d |" % (
-            op[:60], e["launches"], e["avg_ms"], a or "-", "%.0f" % gbs if gbs else "-",
+            op[:60], e["launches"], e["avg_ms"], ("%g" % a) if a else "-", "%.0f" % gbs if gbs else "-",
             "%.1f %%" % (gbs / 80.) if gbs else "-", "%.1f" % (hb / rays) if (hb and rays) else "-",
             "%.3f" % (hb / rays / a) if (hb and rays and a) else "-",
             "%.0f" % e["valu_insts_per_wave"] if "valu_insts_per_wave" in e else "-",
@@ -238,7 +241,7 @@ def main():
                     "BASELINE config 5 share (Arcus petal: segmented source, segmented SPO-pair program exact + fast, grating "
                     "program, focusY), %g rays; the stacked-grating while loop runs on 1e8 rays." % crays),
         "ops": (py + [os.path.join(ROOT, "tools", "bench_ops.py"), "--rays", "1e8", "--reps", "3", "--only",
-                      "woltersine,primaryLL,secondaryLL,wsPrimary,wsSecondary,wsPrimaryB,wsSecondaryB,zernsurf36,zernconic36"],
+                      "woltersine,primaryLL,secondaryLL,wsPrimary,wsSecondary,wsPrimaryB,wsSecondaryB,zernsurf36,zernconic36,LL,W-S"],
                 int(1e8), [], "Legendre-Legendre / Wolter-Schwarzschild / woltersine / Zernike kernels one by one "
                 "(tools/bench_ops.py, 1e8 rays)."),
     }
@@ -259,14 +262,22 @@ def main():
         out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (a.tag, t))
         ks = collect(t, cmd, out)
         write_tables(a.tag, t, ks, rays, note + "  Commit %s, csrc %s." % (a.commit, bench.csrc_hash()), launches)
+        shared = defaultdict(list)
+        for lname, nb in launches:
+            shared[LAUNCH_KERNEL.get(lname)].append(nb)
         for lname, nb in launches:
             op = LAUNCH_KERNEL.get(lname)
             e = ks.get(op)
             if not e:
                 continue
             if "hbm_bytes_per_launch" in e:
-                traffic["kernels"]["%s:%s" % (t, lname)] = {"rays": rays, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
-                                                           "algorithmic_bytes_per_launch": nb * rays, "kernel": op}
+                nbs = shared[op]
+                ent = {"rays": rays, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
+                       "algorithmic_bytes_per_launch": sum(nbs) / len(nbs) * rays, "kernel": op}
+                if len(set(nbs)) > 1:
+                    ent["note"] = ("this kernel runs %d times per chain with different write sets (%s B/ray): both figures "
+                                   "are averages over those launches" % (len(nbs), "/".join(str(b) for b in nbs)))
+                traffic["kernels"]["%s:%s" % (t, lname)] = ent
             if "fp64_flops_per_launch" in e:
                 flops["kernels"]["%s:%s" % (t, lname)] = {"rays": rays, "fp64_flops_per_ray": e["fp64_flops_per_launch"] / rays,
                                                          "valu_insts_per_wave": e.get("valu_insts_per_wave"), "kernel": op}
