@@ -186,6 +186,11 @@ int pxf_wssecondaryback(double *x, double *y, double *z, const double *l, const 
  * Exported so that a CPU test can hold them to libm's atan2 / cos / tan bit for bit. */
 int pxf_host_cos_atan2(const double *r, const double *z, double *beta, double *cosbeta, double *tanhalf,
                        int64_t num);
+/* Host utility (no GPU): theta = atan2(y, x) and sincos(theta) exactly as the back-surface W-S kernels form the
+ * substrate offset (woltsurf.f95:760-763, 862-865): the correctly rounded arctangent and a restatement of the C
+ * library's `sincos` (the non-FMA build of the same algorithm).  NaN for zero / non-finite / extreme operands. */
+int pxf_host_sincos_atan2(const double *y, const double *x, double *theta, double *sintheta, double *costheta,
+                          int64_t num);
 
 /* ---- zernsurf.f95 (+ zernset, specialFunctions.f95:142-232) ------------------------------- */
 

@@ -1428,3 +1428,15 @@ void orc_cos_atan2(const double *r, const double *z, double *beta, double *cosbe
         tanhalf[i] = tan(beta[i] / 2);
     }
 }
+
+/* theta = atan2(y, x), sin(theta), cos(theta) by the C library (gcc merges the pair into one `sincos` call, as    */
+/* flang does in the reference's wsprimaryBack / wssecondaryBack, woltsurf.f95:760-763, 862-865);              */
+/* checker of the product's pxf_host_sincos_atan2.                                                             */
+void orc_sincos_atan2(const double *y, const double *x, double *theta, double *sintheta, double *costheta, int64_t num)
+{
+    extern void sincos(double, double *, double *);   /* glibc; what both compilers emit for the sin/cos pair */
+    for (int64_t i = 0; i < num; i++) {
+        theta[i] = atan2(y[i], x[i]);
+        sincos(theta[i], &sintheta[i], &costheta[i]);
+    }
+}

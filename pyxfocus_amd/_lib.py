@@ -110,6 +110,7 @@ _SIGS = {
     "pxf_program_run_segments": [_P, _i32, _P, _i32, _i64, _PP, _i64, _P],
     "pxf_zernike_monomials": [_DP, _IP, _IP, _i32, _i32, _DP],
     "pxf_host_cos_atan2": [_DP, _DP, _DP, _DP, _DP, _i64],
+    "pxf_host_sincos_atan2": [_DP, _DP, _DP, _DP, _DP, _i64],
     "pxf_fan_search": [_PP, _i64, _d, _d, _d, _d, _i32, _P, _P, _P, _P],
     "pxf_fan_finish": [_PP, _i64, _d, _d, _d, _d, _P, _i32, _P],
     "pxf_program_run_fast": [_P, _i32, _PP, _i64, _P],

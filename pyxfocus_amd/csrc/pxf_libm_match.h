@@ -92,4 +92,141 @@ __host__ __device__ __forceinline__ bool libm_cos_atan2(double r, double z, cons
     return true;
 }
 
+// ---- sincos(atan2(y, x)) at an arbitrary azimuth -------------------------------------------------------------
+// The back-surface variants (woltsurf.f95:760-763, 862-865) shrink the ray's radius by the substrate thickness
+// through `theta = atan2(y, x); x' = (r - thick) cos(theta); y' = (r - thick) sin(theta)` -- compiled (flang and
+// gcc alike) into ONE call of the C library's `sincos`, which in glibc 2.35 is the same IBM algorithm as sin / cos
+// but built WITHOUT fused multiply-adds (no multiarch variant), so it is restated here with plain operations
+// (the translation units that include this header are compiled -ffp-contract=off): Taylor polynomial below 0.126,
+// table + polynomials below 0.855, reflection about pi/2 up to 2.426, Cody-Waite reduction by pi/2 beyond.
+// tests/test_host.py holds it to libm's sincos bit for bit over (-pi, pi].
+__host__ __device__ __forceinline__ double libm_sc_cos(double x, double dx, const double *__restrict__ tab)
+{
+    const double big = 0x1.8p45;
+    const double sn3 = -1.66666666666664880952546298448555E-01, sn5 = 8.33333214285722277379541354343671E-03;
+    const double cs2 = 4.99999999999999999999950396842453E-01, cs4 = -4.16666666666664434524222570944589E-02,
+                 cs6 = 1.38888874007937613028114285595617E-03;
+    if (x < 0) dx = -dx;
+    const double u = big + fabs(x);
+    uint64_t ub;
+    memcpy(&ub, &u, 8);
+    const int k = (int)(uint32_t)(ub & 0xffffffffu) * 4;
+    x = fabs(x) - (u - big) + dx;
+    const double sn = tab[k], ssn = tab[k + 1], cs = tab[k + 2], ccs = tab[k + 3];
+    const double xx = x * x;
+    const double s = x + x * xx * (sn3 + xx * sn5);
+    const double c = xx * (cs2 + xx * (cs4 + xx * cs6));
+    const double cor = (ccs - s * ssn - cs * c) - sn * s;
+    return cs + cor;
+}
+__host__ __device__ __forceinline__ double libm_sc_sin(double x, double dx, const double *__restrict__ tab)
+{
+    const double big = 0x1.8p45;
+    const double sn3 = -1.66666666666664880952546298448555E-01, sn5 = 8.33333214285722277379541354343671E-03;
+    const double cs2 = 4.99999999999999999999950396842453E-01, cs4 = -4.16666666666664434524222570944589E-02,
+                 cs6 = 1.38888874007937613028114285595617E-03;
+    const double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ECEp-7, s3 = -0x1.A01A019DB08B8p-13,
+                 s4 = 0x1.71DE27B9A7ED9p-19, s5 = -0x1.ADDFFC2FCDF59p-26;
+    const double xold = x;
+    if (fabs(x) < 0.126) {
+        const double xx = x * x;
+        const double t = (((((s5 * xx + s4) * xx + s3) * xx + s2) * xx + s1) * x - 0.5 * dx) * xx + dx;
+        return x + t;
+    }
+    if (x <= 0) dx = -dx;
+    const double u = big + fabs(x);
+    uint64_t ub;
+    memcpy(&ub, &u, 8);
+    const int k = (int)(uint32_t)(ub & 0xffffffffu) * 4;
+    x = fabs(x) - (u - big);
+    const double sn = tab[k], ssn = tab[k + 1], cs = tab[k + 2], ccs = tab[k + 3];
+    const double xx = x * x;
+    const double s = x + (dx + x * xx * (sn3 + xx * sn5));
+    const double c = x * dx + xx * (cs2 + xx * (cs4 + xx * cs6));
+    const double cor = (ssn + s * ccs - sn * c) + cs * s;
+    return copysign(sn + cor, xold);
+}
+// glibc s_sincos.c for 2^-27 <= |x| < 105414350 (here: |x| <= pi)
+__host__ __device__ __forceinline__ void libm_sincos(double x, const double *__restrict__ tab, double &sinx, double &cosx)
+{
+    const double hp0 = 0x1.921FB54442D18p0, hp1 = 0x1.1A62633145C07p-54;
+    const double mp1 = 0x1.921FB58000000p0, mp2 = -0x1.DDE973C000000p-27, pp3 = -0x1.CB3B398000000p-55,
+                 pp4 = -0x1.d747f23e32ed7p-83, hpinv = 0x1.45F306DC9C883p-1, toint = 0x1.8p52;
+    const double ax = fabs(x);
+    if (ax < 0x1p-27) {
+        sinx = x;
+        cosx = 1.;
+    } else if (ax < 0.85546875) {
+        sinx = libm_sc_sin(x, 0., tab);
+        cosx = libm_sc_cos(x, 0., tab);
+    } else if (ax < 0x1.368fdp+1) {   // high word < 0x400368fd: 2.426265
+        const double y = hp0 - ax, a = y + hp1, da = (y - a) + hp1;
+        sinx = copysign(libm_sc_cos(a, da, tab), x);
+        cosx = libm_sc_sin(a, da, tab);
+    } else {
+        const double t = x * hpinv + toint, xn = t - toint;
+        uint64_t tb;
+        memcpy(&tb, &t, 8);
+        int n = (int)(tb & 3);
+        const double y = (x - xn * mp1) - xn * mp2;
+        double t1 = xn * pp3;
+        const double t2 = y - t1;
+        double db = (y - t2) - t1;
+        t1 = xn * pp4;
+        const double b = t2 - t1;
+        db += (t2 - b) - t1;
+        const double r0 = (n & 1) ? libm_sc_cos(b, db, tab) : libm_sc_sin(b, db, tab);
+        sinx = (n & 2) ? -r0 : r0;
+        n++;
+        const double r1 = (n & 1) ? libm_sc_cos(b, db, tab) : libm_sc_sin(b, db, tab);
+        cosx = (n & 2) ? -r1 : r1;
+    }
+}
+
+// theta = atan2(y, x), correctly rounded (double-double: octant reduction, reduction against tan(k/128), short
+// series; pi/2 and pi as head + tail) -- what glibc's atan2 returns in all but ~2e-3 of the cases -- then
+// cos(theta), sin(theta) by libm_sincos.  false: a zero / non-finite / extreme operand (the caller uses ocml).
+__host__ __device__ __forceinline__ bool libm_sincos_atan2(double y, double x, const double *__restrict__ sincos_tab,
+                                                           const double *__restrict__ tan_tab, double &theta,
+                                                           double &sinth, double &costh)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    if (!(ax > 1e-150 && ay > 1e-150 && ax < 1e150 && ay < 1e150)) return false;
+    const bool swap = ay > ax;
+    const double num = swap ? ax : ay, den = swap ? ay : ax;    // t = num / den in (0, 1]
+    const double th = num / den;
+    if (!(th > 1e-100)) return false;
+    const double tl = fma(-th, den, num) / den;
+    int k0 = (int)rintf(atanf((float)th) * 128.f);
+    k0 = k0 > PXF_TRIG_TAB_N - 1 ? PXF_TRIG_TAB_N - 1 : k0;
+    const double xi = k0 * 0.0078125, Th = tan_tab[2 * k0], Tl = tan_tab[2 * k0 + 1];
+    const double s = th - Th, bb = s - th;
+    const double e = ((th - (s - bb)) + (-Th - bb)) + (tl - Tl);
+    const double ph = th * Th, pl = fma(th, Th, -ph) + (th * Tl + tl * Th);
+    const double dh = 1. + ph, dl = ((1. - dh) + ph) + pl;
+    const double wh = s / dh;
+    const double wl = (fma(-wh, dh, s) + e - wh * dl) / dh;
+    const double w2 = wh * wh;
+    const double p = wh * w2 * (-1. / 3 + w2 * (0.2 + w2 * (-1. / 7 + w2 * (1. / 9 - w2 * (1. / 11)))));
+    // atan(t) = rh + rl
+    double rh = xi + wh;
+    const double b2 = rh - xi;
+    double rl = ((xi - (rh - b2)) + (wh - b2)) + (wl + p);
+    const double hp0 = 0x1.921FB54442D18p0, hp1 = 0x1.1A62633145C07p-54;
+    if (swap) {            // pi/2 - r
+        const double q = hp0 - rh, c2 = q - hp0;
+        rl = ((hp0 - (q - c2)) + (-rh - c2)) + (hp1 - rl);
+        rh = q;
+    }
+    if (x < 0) {           // pi - r
+        const double q = 2 * hp0 - rh, c2 = q - 2 * hp0;
+        rl = ((2 * hp0 - (q - c2)) + (-rh - c2)) + (2 * hp1 - rl);
+        rh = q;
+    }
+    const double r = rh + rl;
+    theta = y < 0 ? -r : r;
+    libm_sincos(theta, sincos_tab, sinth, costh);
+    return true;
+}
+
 }  // namespace pxf

@@ -329,11 +329,15 @@ struct WSOp {
             while (fabs(delt) > PXF_TOL_1EM8) {
                 const double xa = c[X], ya = c[Y], z = c[Z];
                 double x = xa, y = ya;
-                if (BACK) {  // (rb - thick) * (cos, sin)(atan2(ya, xa))
+                if (BACK) {  // (rb - thick) * (cos, sin)(atan2(ya, xa)), woltsurf.f95:760-763 / 862-865
                     const double rb = sqrt(xa * xa + ya * ya);
-                    const double sc = (rb - thick) / rb;
-                    x = sc * xa;
-                    y = sc * ya;
+                    // theta and its sincos with the C library's own rounding (pxf_libm_match.h): the secondary's F
+                    // is quantised by (1 - cos beta), so an ulp of x, y here decides which quantum a ray whose
+                    // first steps land on the mirror's edge ends in
+                    double th, sn, cs;
+                    if (!libm_sincos_atan2(ya, xa, c_sincos_tab, c_tan_tab, th, sn, cs)) sincos(atan2(ya, xa), &sn, &cs);
+                    x = (rb - thick) * cs;
+                    y = (rb - thick) * sn;
                 }
                 const double r2 = x * x + y * y;
                 const double rr = sqrt(r2);

@@ -343,6 +343,16 @@ int pxf_host_cos_atan2(const double *r, const double *z, double *beta, double *c
     return PXF_OK;
 }
 
+int pxf_host_sincos_atan2(const double *y, const double *x, double *theta, double *sintheta, double *costheta,
+                          int64_t num)
+{
+    if (num < 0 || (num > 0 && (!y || !x || !theta || !sintheta || !costheta))) return PXF_EINVAL;
+    for (int64_t i = 0; i < num; i++)
+        if (!libm_sincos_atan2(y[i], x[i], h_sincos_tab, h_tan_tab, theta[i], sintheta[i], costheta[i]))
+            theta[i] = sintheta[i] = costheta[i] = NAN;
+    return PXF_OK;
+}
+
 int pxf_wsprimary(double *x, double *y, double *z, const double *l, const double *m, const double *n,
                   double *ux, double *uy, double *uz, int64_t num, double alpha, double z0, double psi,
                   const uint8_t *mask, pxf_stream_t stream)

@@ -340,3 +340,41 @@ def test_ws_secondary_cos_beta_matches_libm_bitwise():
     assert _lib.lib().pxf_host_cos_atan2(r.ctypes.data_as(dp), z.ctypes.data_as(dp), b.ctypes.data_as(dp),
                                          c.ctypes.data_as(dp), t.ctypes.data_as(dp), 4) == 0
     assert np.isnan(b).all() and np.isnan(c).all() and np.isnan(t).all()
+
+
+def test_ws_back_sincos_atan2_matches_libm_bitwise():
+    """The back-surface W-S variants offset the ray's radius through theta = atan2(y, x), sincos(theta)
+    (woltsurf.f95:760-763, 862-865); for the secondary an ulp of that offset decides the quantum of F a ray ends in
+    (DESIGN.md section 4).  Host copy of the kernels' routine (pxf_host_sincos_atan2: correctly rounded arctangent +
+    a restatement of glibc's non-FMA `sincos`) against libm on THIS machine over every quadrant: theta equal in all
+    but 5e-3 of the cases (libm's atan2 is not always the correctly rounded one) and never further than the
+    neighbouring double; sin and cos bit for bit wherever theta agrees."""
+    import ctypes as C
+    from oracle import api
+    from pyxfocus_amd import _lib
+    olib = C.CDLL(os.path.join(os.path.dirname(api.__file__), "libpxf_oracle.so"))
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(78)
+    n = 600_000
+    ang = rng.uniform(-np.pi, np.pi, n)
+    ang[: n // 6] = np.sign(ang[: n // 6]) * (np.pi / 2 + rng.normal(0, 1e-3, n // 6))      # around +-pi/2
+    ang[n // 6: n // 3] = np.sign(ang[n // 6: n // 3]) * (np.pi - np.abs(rng.normal(0, 1e-3, n // 6)))   # near +-pi
+    ang[n // 3: n // 2] = rng.normal(0, 1e-2, n // 2 - n // 3)                              # small angles
+    rad = rng.uniform(100., 1200., n)
+    x, y = rad * np.cos(ang), rad * np.sin(ang)
+    t_ref, s_ref, c_ref, t_got, s_got, c_got = (np.empty(n) for _ in range(6))
+    olib.orc_sincos_atan2(y.ctypes.data_as(dp), x.ctypes.data_as(dp), t_ref.ctypes.data_as(dp), s_ref.ctypes.data_as(dp),
+                          c_ref.ctypes.data_as(dp), C.c_int64(n))
+    assert _lib.lib().pxf_host_sincos_atan2(y.ctypes.data_as(dp), x.ctypes.data_as(dp), t_got.ctypes.data_as(dp),
+                                            s_got.ctypes.data_as(dp), c_got.ctypes.data_as(dp), n) == 0
+    assert not np.isnan(t_got).any()
+    same = t_got == t_ref
+    assert same.mean() > 0.995, same.mean()
+    assert (np.abs(t_got - t_ref) <= np.spacing(np.abs(t_ref))).all()
+    assert np.array_equal(s_got[same], s_ref[same]) and np.array_equal(c_got[same], c_ref[same])
+    # zero / non-finite operands: NaN (the kernels then call ocml)
+    yy = np.array([0., 1., np.inf, np.nan]); xx = np.array([1., 0., 1., 1.])
+    t, s_, c_ = np.empty(4), np.empty(4), np.empty(4)
+    assert _lib.lib().pxf_host_sincos_atan2(yy.ctypes.data_as(dp), xx.ctypes.data_as(dp), t.ctypes.data_as(dp),
+                                            s_.ctypes.data_as(dp), c_.ctypes.data_as(dp), 4) == 0
+    assert np.isnan(t).all()
