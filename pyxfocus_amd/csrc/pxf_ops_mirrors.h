@@ -398,7 +398,7 @@ struct WSOp {
                         flag = cb >= cbs;                     // beta <= betas
                     }
                     if (flag) {
-                        F = -z + cbs * ff;  // cos(betas) / a, a = 1/ff
+                        F = -z + cbs / (1 / ff);  // cos(betas) / a with a = 1/ff, in the reference's two roundings (:513,521)
                         const double dadbs = sbs / ff / (1 - cbs) + (k + 1) * (cbs + 1) * tb2s / (cb2s * cb2s) / 2 / g / k;
                         const double dbdzs = -(sbs * sbs) / rr;
                         const double gam = (-ff * sbs - ff * ff * cbs * dadbs) * dbdzs;
