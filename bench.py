@@ -233,7 +233,7 @@ def parity_vs_checker(chain_np, chain_dev, make_cols, dev, tol_note):
 
 
 def bench_config3(n, steps, dev, pxf, sources, tran, surf, con):
-    """BASELINE config 3: config-2 chain + one radial grating stage, 12 launches, 1128 B/ray."""
+    """BASELINE config 3: config-2 chain + one radial grating stage, 12 launches, 1080 B/ray."""
     rin, rout = float(con.primrad(Z0, R0, Z0)), float(con.primrad(Z0 + LMIR, R0, Z0))
     fresh = lambda seed: sources.subannulus(rin, rout, 0.5, n, zhat=-1., rng="philox", seed=seed)
     per, fms = [], []

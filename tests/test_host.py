@@ -157,7 +157,8 @@ def test_bench_cli_and_chain_definition():
     from tools import workloads as wl
     # SURVEY 8(d) books 576 / 1192 with every transform at 144 B; the leading pure translation moves 80
     assert sum(b for _, b in wl.CONFIG2) == wl.BYTES["config2"] == wl.SURVEY_BYTES["config2"] - 64 == 512
-    assert sum(b for _, b in wl.CONFIG3) == wl.BYTES["config3"] == wl.SURVEY_BYTES["config3"] - 64 == 1128
+    # ... and the grating stage's two frame changes rotate about x only: 24 B each not rewritten
+    assert sum(b for _, b in wl.CONFIG3) == wl.BYTES["config3"] == wl.SURVEY_BYTES["config3"] - 64 - 48 == 1080
     assert sum(b for _, b in wl.CONFIG4) == wl.BYTES["config4"] == 264
     assert len(mod.csrc_hash()) == 16
     # --gpus N without a launcher must start the ranks itself, before any GPU call

@@ -181,8 +181,10 @@ def write_tables(tag, target, ks, rays, note, launch_bytes):
     for op in ks:                                   # surface intersections: 6 columns in, 6 out
         if op.split("<")[0] in ("LLOp", "WSOp", "WolterSineOp", "ZernOpSel", "WolterPrimaryOp", "WolterSecondaryOp"):
             alg.setdefault(op, 96)
-        if op.split("<")[0] == "program_mirror_kernel":
-            alg.setdefault(op, 120)                 # a mirror pair with its frame changes: 6 columns in, 9 out
+        if op == "program_mirror_kernel<12, true>":
+            alg.setdefault(op, 120)                 # the L-L pair of tools/bench_ops.py: 6 columns in, 9 out
+        if op == "program_mirror_kernel<0, true>":
+            alg.setdefault(op, 144)                 # the W-S pair: 9 in (a failed W-S ray keeps its normal), 9 out
         if op.split("<")[0] in ("program_kernel", "program_zern_kernel", "program_fast_kernel") and target not in ("ops", "config5"):
             alg.setdefault(op, 120)                 # the configs' programs: 6 columns in, 9 out
         if op.split("<")[0] in ("program_seg_kernel", "program_fast_seg_kernel"):

@@ -16,15 +16,16 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6                # MI355X fp64 vector peak (SURVEY 
 # The chain's leading `transform(rays, 0, 0, -(z0 + 2L), 0, 0, 0)` is a pure translation along z: all nine numbers
 # are read and go through the reference's arithmetic, but only z comes back different, and the kernel stores only
 # what changed (TransformOp, pxf_ops_transforms.h): 72 B read + 8 B written = 80 B/ray, where SURVEY 8(d) booked
-# the general 144 (the frame changes of the grating stage rotate, change everything and move 144).
+# the general 144 (the PMC traffic confirms both: profiles/r02d_config{2,3}_kernels.md).
 SURVEY_BYTES = {"config2": 576, "config3": 1192}     # SURVEY 8(d)'s own figures, every transform booked at 144
 CONFIG2 = [("transform", 80), ("wolterprimary", 96), ("reflect", 72), ("woltersecondary", 96), ("reflect", 72),
            ("flat", 96)]
-CONFIG3_TAIL = [("transform(g)", 144), ("flat(g)", 96), ("reflect(g)", 72), ("radgrat", 64), ("itransform(g)", 144),
+# the grating stage's frame changes rotate about x only: x, l, ux come back unchanged and are not rewritten (120 B)
+CONFIG3_TAIL = [("transform(g)", 120), ("flat(g)", 96), ("reflect(g)", 72), ("radgrat", 64), ("itransform(g)", 120),
                 ("flat(focal)", 96)]
 CONFIG3 = CONFIG2 + CONFIG3_TAIL
 CONFIG4 = [("zernsurf", 96), ("reflect", 72), ("flat", 96)]
-BYTES = {"config2": 512, "config3": 1128, "config4": 264}
+BYTES = {"config2": 512, "config3": 1080, "config4": 264}
 # one launch: 6 columns in (x y z l m n), 9 out; the Zernike program reads the same six
 FUSED_BYTES = {"config2": 120, "config3": 120, "config4": 120}
 
