@@ -336,6 +336,9 @@ def compile_segments(rays, rays_per_seg, fn, params, fast=False):
             _tls.rec = None
         if rec.launches or not rec.ops:
             raise _lib.PxfError("compile_segments: the segment function issued a call that cannot be fused")
+        if rec.has_zern or rec.has_mirror:
+            raise _lib.PxfError("compile_segments: a Zernike trace / W-S / Legendre-Legendre / woltersine mirror carries "
+                                "its own tables and cannot be a per-segment operation")
         if any(o.mask or (o.aux and o.code not in AUX_OUT_CODES) for o in rec.ops):
             raise _lib.PxfError("compile_segments: ind= masks / per-ray input columns are not supported per segment")
         # output columns (indAngle(..., out=)): segment s must write the s-th slice of ONE bundle-long column

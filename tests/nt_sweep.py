@@ -4,8 +4,8 @@
 Must be started with PXF_NT_MIN_RAYS=0 in the environment: the library then launches the NT=true
 instantiation of every ray kernel (non-temporal loads / stores -- what every bundle above 3.3M rays
 runs) even for the small bundles the oracle can check.  Re-runs, on those code objects: every case of
-oracle/cases.py plain and masked, the fused two-bounce program, and the Zernike sweep over all 15
-radial orders plain and masked.  Prints "nt sweep ok" and exits 0, or raises."""
+oracle/cases.py plain and masked, the fused two-bounce program, the programs that hold mirrors, and the
+Zernike sweep over all 15 radial orders plain and masked.  Prints "nt sweep ok" and exits 0, or raises."""
 import os
 import sys
 
@@ -81,12 +81,36 @@ def main():
                 assert np.abs(u - v).max() <= 1e-9 * (1 + np.abs(u).max()), k
             else:
                 assert bits_equal(u, v).all(), k
+    # programs that hold W-S / Legendre-Legendre / woltersine mirrors, NT instantiations: one launch == five launches
+    import pyxfocus_amd.surfaces as surf
+    import pyxfocus_amd.transformations as tran
+    nmirror = 0
+    for name, fn, cols, args in cases.cases(num=2001, seed=31):
+        if not any(t_ in fn for t_ in ("ws", "ll", "woltersine")):
+            continue
+
+        def mchain(t):
+            rays = [t[k] for k in ALLCOLS]
+            tran.transform(rays, 1e-3, -2e-3, 0., 1e-6, -1e-6, 0.)
+            call_gpu(fn, t, args)
+            tran.reflect(rays)
+            tran.itransform(rays, 1e-3, -2e-3, 0., 1e-6, -1e-6, 0.)
+            surf.flat(rays)
+        a_, b_ = to_dev(cols), to_dev(cols)
+        mchain(a_)
+        with pxf.fused() as rec:
+            mchain(b_)
+        assert rec.launches == 1 and rec.fused_ops == 5, (name, rec.launches)
+        for k in ALLCOLS:
+            assert bits_equal(a_[k].cpu().numpy(), b_[k].cpu().numpy()).all(), ("nt mirror program", name, k)
+        nmirror += 1
+    assert nmirror == 8
     for nmax in range(1, 16):
         zernike_order_check(port, nmax)
         zernike_order_check(port, nmax, masked=True)
     torch.cuda.synchronize()
     print("nt sweep ok: %d cases x (plain, masked), fused chain exact + fast, segmented SPO exact + fast, "
-          "15 Zernike orders x (plain, masked, fused)" % ncase)
+          "8 mirror programs, 15 Zernike orders x (plain, masked, fused)" % ncase)
 
 
 if __name__ == "__main__":
