@@ -28,6 +28,8 @@ and the outputs the reference produced for them.  No reference source text is st
                      reference's own modules: Zernike wavefront (OPD), misaligned primary / pair, applyT, centroids.
   ws_heights.npz     examples/ws_axial_heights.py (examples/axro/axialHeights.py:50-133) through the reference's own
                      modules: W-S radius probes, off-axis W-S pair, focusI, hpd, rmsCentroid.
+  retrace.npz        examples/retrace_error.py (examples/axro/retraceError.py:20-65) through the reference's own modules:
+                     pointTo, double pass of a misaligned / Legendre-deformed primary off a retro-reflector.
   config5.npz        a small Arcus-style multi-shell trace (sector.py:540-757 call shape) through
                      the reference's own surfaces.py / transformations.py / analyses.py wrappers
                      over the compiled Fortran: per-shell SPO pair, grating stage, focusY.
@@ -312,16 +314,44 @@ def gold_ws_heights(tran, src, anal, surf):
     print("ws_heights: primrad %s, traceZeta(onaxis) %s" % (blob["primrad"][:2], blob["onaxis/scalars"]))
 
 
+RETRACE_CASES = (("perfect", {}), ("tilted", dict(primalign=np.array([0., 0., 0., 2e-5, -1e-5, 0.]))),
+                 ("shifted", dict(primalign=np.array([.02, -.01, .5, 0., 0., 0.]))),
+                 ("figure", dict(primCoeffs=(np.array([2e-4, -1e-4, 5e-5, 3e-5]), np.array([1, 2, 0, 3]), np.array([0, 0, 2, 1])))),
+                 ("figure+tilt", dict(primCoeffs=(np.array([2e-4, -1e-4, 5e-5, 3e-5]), np.array([1, 2, 0, 3]), np.array([0, 0, 2, 1])),
+                                      primalign=np.array([0., 0., 0., -1e-5, 2e-5, 1e-4]))))
+
+
+def gold_retrace(tran, src, anal, surf):
+    """examples/retrace_error.py (the reference's examples/axro/retraceError.py:20-65) on the reference's own
+    modules: pointTo(reverse=1.), a double pass of a (misaligned, Legendre-deformed) Wolter primary off a flat
+    retro-reflector, the dropped vignette, the primary's focus."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import retrace_error as R
+    a = R.Api(src, surf, tran, anal, np, sys.modules["PyXFocus.conicsolve"])
+    blob = {}
+    for tag, kw in RETRACE_CASES:
+        np.random.seed(6)
+        rays, theta = R.tracePrimary(a, num=3000, **kw)
+        for k, v in zip(cases.ALLCOLS, rays):
+            blob["%s/%s" % (tag, k)] = np.asarray(v)
+        blob[tag + "/theta"] = theta
+        blob[tag + "/scalars"] = np.array(list(anal.centroid(rays)) + [anal.rmsCentroid(rays)])
+    np.savez_compressed(os.path.join(OUT, "retrace.npz"), **blob)
+    print("retrace: centroid+rms perfect %s, tilted %s" % (blob["perfect/scalars"], blob["tilted/scalars"]))
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5, alignment, ws_heights")
+    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5, alignment, ws_heights, retrace")
     only = [t for t in ap.parse_args().only.split(",") if t]
     os.makedirs(OUT, exist_ok=True)
     ref = api.load_ref()
     tran, src = shim_reference_python(ref)
-    if not only or set(only) & {"analyses", "config5", "alignment", "ws_heights"}:
+    if not only or set(only) & {"analyses", "config5", "alignment", "ws_heights", "retrace"}:
         anal, surf = shim_reference_analyses(ref)
+        if not only or "retrace" in only:
+            gold_retrace(tran, src, anal, surf)
         if not only or "alignment" in only:
             gold_alignment(tran, src, anal, surf)
         if not only or "ws_heights" in only:

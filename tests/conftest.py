@@ -43,4 +43,4 @@ def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
     return {k: np.load(os.path.join(d, k + ".npz")) for k in
-            ("native_cases", "chain_config2", "config1", "wrappers", "sources", "wavefront", "design", "analyses", "config5", "alignment", "ws_heights")}
+            ("native_cases", "chain_config2", "config1", "wrappers", "sources", "wavefront", "design", "analyses", "config5", "alignment", "ws_heights", "retrace")}

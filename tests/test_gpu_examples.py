@@ -181,3 +181,28 @@ def test_ws_axial_heights_example_equals_reference_python(golden):
     np.random.seed(4)
     nout, zmean = W.onaxisMerit(api, 1e4 + 50., float(g["onaxis/scalars"][1]), num=1500)
     assert nout == int(g["merit"][0]) and abs(zmean - g["merit"][1]) < 2e-8
+
+
+def test_retrace_error_example_equals_reference_python(golden):
+    """examples/retrace_error.py (retraceError.py:20-65: point source at the primary's focus -> pointTo -> primary
+    -> flat retro-reflector -> primary again -> focus, with six-DoF misalignments and a Legendre-Legendre figure)
+    on pyxfocus_amd against the fixture the SAME code produced on the reference's own modules (retrace.npz).
+    Same NumPy source stream, so the bundles correspond ray by ray; the dropped vignette keeps every ray."""
+    import retrace_error as R
+    from oracle.make_golden import RETRACE_CASES
+    import pyxfocus_amd.analyses as anal
+    g = golden["retrace"]
+    api = R.Api.amd()
+    for tag, kw in RETRACE_CASES:
+        np.random.seed(6)
+        rays, theta = R.tracePrimary(api, num=3000, **kw)
+        assert len(rays[1]) == 3000
+        assert np.abs(theta.cpu().numpy() - g[tag + "/theta"]).max() < 1e-14
+        for k, v in zip(ALLCOLS, rays):
+            w = g["%s/%s" % (tag, k)]
+            assert np.array_equal(np.isnan(v.cpu().numpy()), np.isnan(w)), (tag, k)
+            f = ~np.isnan(w)
+            assert np.abs(v.cpu().numpy()[f] - w[f]).max() <= 2e-9 * (1 + np.abs(w[f]).max()), (tag, k)
+        cx, cy = anal.centroid(rays)
+        want = g[tag + "/scalars"]
+        assert abs(cx - want[0]) < 1e-9 and abs(cy - want[1]) < 1e-9 and abs(anal.rmsCentroid(rays) - want[2]) < 1e-9, tag
