@@ -73,6 +73,95 @@ __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, 
     }
 }
 
+// ---- straight-line programs ---------------------------------------------------------------------
+// The interpreter pays for its generality: a `switch` per operation and, at every join, a block of phi copies of
+// the whole ray state -- ~300 of the 1166 VALU wave-instructions of the two-bounce program (PMC), on a kernel
+// that is VALU-bound.  The operation SEQUENCES of the BASELINE configs are known at compile time, so each gets a
+// kernel in which the same Op::apply bodies follow one another with no dispatch at all (a fold over the code list);
+// parameters, load / store sets and the transform groups the planner dropped still come from the planned program,
+// so results are the interpreter's bit for bit.  pxf_program_run picks the chain kernel when an unmasked
+// program's code sequence equals one of the lists below.
+template <int CODE, int V, bool NT>
+__device__ __forceinline__ void exec_fixed(const ProgOp &o, int64_t vv, Ray (&r)[V], const bool (&sel)[V])
+{
+    const double *__restrict__ P = o.p;
+    if constexpr (CODE == PXF_OP_FLAT) run_op(FlatOp<false>{0.}, r, sel);
+    else if constexpr (CODE == PXF_OP_WOLTERPRIMARY) run_op(WolterPrimaryOp<false>{P[0], P[1], P[2], 0.}, r, sel);
+    else if constexpr (CODE == PXF_OP_WOLTERSECONDARY) run_op(WolterSecondaryOp{P[0], P[1], P[2]}, r, sel);
+    else if constexpr (CODE == PXF_OP_TRANSFORM)
+        run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], o.flags & 7}, r, sel);
+    else if constexpr (CODE == PXF_OP_ITRANSFORM)
+        run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], o.flags & 7}, r, sel);
+    else if constexpr (CODE == PXF_OP_REFLECT) run_op(ReflectOp{}, r, sel);
+    else if constexpr (CODE == PXF_OP_RADGRAT) run_op(RadgratOp<false>{P[0], P[1], P[2], P[3], P[4]}, r, sel);
+    else static_assert(CODE == PXF_OP_FLAT, "operation not available in a straight-line program");
+}
+
+template <int V, bool NT, int... CODES>
+__global__ __launch_bounds__(kBlock) void program_chain_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        const int64_t vv = first + v;
+        Ray r[V];
+#pragma unroll
+        for (int col = 0; col < 10; col++) {
+            if (pg.load & B(col)) {  // wave-uniform
+                double t[V];
+                load_col<V, NT>(c.p[col], vv, t);
+#pragma unroll
+                for (int k = 0; k < V; k++) r[k].c[col] = t[k];
+            }
+        }
+        bool sel[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) sel[k] = true;
+        int i = 0;
+        ((exec_fixed<CODES, V, NT>(pg.op[i], vv, r, sel), i++), ...);
+#pragma unroll
+        for (int col = 0; col < 10; col++) {
+            if (pg.store & B(col)) {
+                double t[V];
+                bool w[V];
+#pragma unroll
+                for (int k = 0; k < V; k++) {
+                    t[k] = r[k].c[col];
+                    w[k] = true;
+                }
+                store_col<V, NT>(c.p[col], vv, t, w);
+            }
+        }
+    }
+}
+
+template <int... CODES>
+struct Chain {
+    static constexpr int n = sizeof...(CODES);
+    static bool matches(const Program &pg)
+    {
+        constexpr int codes[] = {CODES...};
+        if (pg.nops != n) return false;
+        for (int i = 0; i < n; i++)
+            if (pg.op[i].code != codes[i] || pg.op[i].mask != nullptr) return false;
+        return true;
+    }
+    template <int V, bool NT>
+    static void launch(hipStream_t s, const Cols &c, int64_t first, int64_t nvec, const Program &pg)
+    {
+        hipLaunchKernelGGL((program_chain_kernel<V, NT, CODES...>), dim3(grid_for(nvec)), dim3(kBlock), 0, s, c, first,
+                           nvec, pg);
+    }
+};
+// BASELINE config 2: transform, wolterprimary, reflect, woltersecondary, reflect, flat
+using ChainTwoBounce = Chain<PXF_OP_TRANSFORM, PXF_OP_WOLTERPRIMARY, PXF_OP_REFLECT, PXF_OP_WOLTERSECONDARY, PXF_OP_REFLECT,
+                             PXF_OP_FLAT>;
+// the grating stage of configs 3 / 5: transform, flat, reflect, radgrat, itransform, flat
+using ChainGrating = Chain<PXF_OP_TRANSFORM, PXF_OP_FLAT, PXF_OP_REFLECT, PXF_OP_RADGRAT, PXF_OP_ITRANSFORM, PXF_OP_FLAT>;
+// BASELINE config 3: the two in a row
+using ChainTwoBounceGrating = Chain<PXF_OP_TRANSFORM, PXF_OP_WOLTERPRIMARY, PXF_OP_REFLECT, PXF_OP_WOLTERSECONDARY,
+                                    PXF_OP_REFLECT, PXF_OP_FLAT, PXF_OP_TRANSFORM, PXF_OP_FLAT, PXF_OP_REFLECT,
+                                    PXF_OP_RADGRAT, PXF_OP_ITRANSFORM, PXF_OP_FLAT>;
+
 // ---- segmented program --------------------------------------------------------------------
 // One launch for a bundle made of contiguous SEGMENTS of `rps` rays (mirror shells, modules ...)
 // that run the same operation sequence with different parameters -- the reference does this as
@@ -461,9 +550,29 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
             else PXF_PLAUNCH(V, false, false, FIRST, NVEC);     \
         }                                                  \
     } while (0)
-    if (nvec2 > 0) PXF_PLAUNCH_V(2, (int64_t)0, nvec2);
-    const int64_t done = nvec2 * 2;
-    if (done < num) PXF_PLAUNCH_V(1, done, num - done);
+    static const bool no_chain = getenv("PXF_PROGRAM_NO_CHAIN") != nullptr;   // dev knob (A/B against the interpreter)
+    bool chained = false;
+#define PXF_TRY_CHAIN(CH)                                                                  \
+    if (!chained && !no_chain && CH::matches(pg)) {                                        \
+        chained = true;                                                                    \
+        if (nvec2 > 0) {                                                                   \
+            if (nt) CH::launch<2, true>(s, c, (int64_t)0, nvec2, pg);                      \
+            else CH::launch<2, false>(s, c, (int64_t)0, nvec2, pg);                        \
+        }                                                                                  \
+        if (nvec2 * 2 < num) {                                                             \
+            if (nt) CH::launch<1, true>(s, c, nvec2 * 2, num - nvec2 * 2, pg);             \
+            else CH::launch<1, false>(s, c, nvec2 * 2, num - nvec2 * 2, pg);               \
+        }                                                                                  \
+    }
+    PXF_TRY_CHAIN(ChainTwoBounce)
+    PXF_TRY_CHAIN(ChainGrating)
+    PXF_TRY_CHAIN(ChainTwoBounceGrating)
+#undef PXF_TRY_CHAIN
+    if (!chained) {
+        if (nvec2 > 0) PXF_PLAUNCH_V(2, (int64_t)0, nvec2);
+        const int64_t done = nvec2 * 2;
+        if (done < num) PXF_PLAUNCH_V(1, done, num - done);
+    }
 #undef PXF_PLAUNCH_V
 #undef PXF_PLAUNCH
     hipError_t e = hipGetLastError();
