@@ -82,19 +82,26 @@ __global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, 
 // so results are the interpreter's bit for bit.  pxf_program_run picks the chain kernel when an unmasked
 // program's code sequence equals one of the lists below.
 template <int CODE, int V, bool NT>
-__device__ __forceinline__ void exec_fixed(const ProgOp &o, int64_t vv, Ray (&r)[V], const bool (&sel)[V])
+__device__ __forceinline__ void exec_fixed(int flags, const double *__restrict__ P, const double *__restrict__ aux,
+                                           int64_t vv, Ray (&r)[V], const bool (&sel)[V])
 {
-    const double *__restrict__ P = o.p;
     if constexpr (CODE == PXF_OP_FLAT) run_op(FlatOp<false>{0.}, r, sel);
     else if constexpr (CODE == PXF_OP_WOLTERPRIMARY) run_op(WolterPrimaryOp<false>{P[0], P[1], P[2], 0.}, r, sel);
     else if constexpr (CODE == PXF_OP_WOLTERSECONDARY) run_op(WolterSecondaryOp{P[0], P[1], P[2]}, r, sel);
     else if constexpr (CODE == PXF_OP_TRANSFORM)
-        run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], o.flags & 7}, r, sel);
+        run_op(TransformOp<false>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
     else if constexpr (CODE == PXF_OP_ITRANSFORM)
-        run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], o.flags & 7}, r, sel);
+        run_op(TransformOp<true>{P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], flags & 7}, r, sel);
     else if constexpr (CODE == PXF_OP_REFLECT) run_op(ReflectOp{}, r, sel);
     else if constexpr (CODE == PXF_OP_RADGRAT) run_op(RadgratOp<false>{P[0], P[1], P[2], P[3], P[4]}, r, sel);
-    else static_assert(CODE == PXF_OP_FLAT, "operation not available in a straight-line program");
+    else if constexpr (CODE == PXF_OP_SPOCONE) run_op(SpoConeOp{P[0], P[1], P[2], P[3]}, r, sel);
+    else if constexpr (CODE == PXF_OP_INDANGLE) {  // an OUTPUT column: the angle of each ray as it stands here
+        run_op(IndAngleOp{(int)P[0]}, r, sel);
+        double t[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) t[k] = r[k].c[AUX];
+        store_col<V, NT>(const_cast<double *>(aux), vv, t, sel);
+    } else static_assert(CODE == PXF_OP_FLAT, "operation not available in a straight-line program");
 }
 
 template <int V, bool NT, int... CODES>
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void program_chain_kernel(Cols c, int64_t f
 #pragma unroll
         for (int k = 0; k < V; k++) sel[k] = true;
         int i = 0;
-        ((exec_fixed<CODES, V, NT>(pg.op[i], vv, r, sel), i++), ...);
+        ((exec_fixed<CODES, V, NT>(pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r, sel), i++), ...);
 #pragma unroll
         for (int col = 0; col < 10; col++) {
             if (pg.store & B(col)) {
@@ -162,6 +169,10 @@ using ChainTwoBounceGrating = Chain<PXF_OP_TRANSFORM, PXF_OP_WOLTERPRIMARY, PXF_
                                     PXF_OP_REFLECT, PXF_OP_FLAT, PXF_OP_TRANSFORM, PXF_OP_FLAT, PXF_OP_REFLECT,
                                     PXF_OP_RADGRAT, PXF_OP_ITRANSFORM, PXF_OP_FLAT>;
 
+// the Arcus SPO pair per shell (segmented programs): rotate, spoCone, reflect, graze, spoCone, reflect, graze, move
+using ChainSpoPair = Chain<PXF_OP_TRANSFORM, PXF_OP_SPOCONE, PXF_OP_REFLECT, PXF_OP_INDANGLE, PXF_OP_SPOCONE, PXF_OP_REFLECT,
+                           PXF_OP_INDANGLE, PXF_OP_TRANSFORM>;
+
 // ---- segmented program --------------------------------------------------------------------
 // One launch for a bundle made of contiguous SEGMENTS of `rps` rays (mirror shells, modules ...)
 // that run the same operation sequence with different parameters -- the reference does this as
@@ -177,7 +188,8 @@ struct SegInfo {
     int nseg;
 };
 
-template <bool NT, bool ANYMASK, bool HOT = false>
+// CODES...: a compile-time operation sequence (straight-line form, see above); empty = the interpreter
+template <bool NT, bool ANYMASK, bool HOT = false, int... CODES>
 __global__ __launch_bounds__(kBlock) void program_seg_kernel(Cols c, int64_t nvec, Program pg, SegInfo sg)
 {
     constexpr int V = 2;
@@ -208,6 +220,13 @@ __global__ __launch_bounds__(kBlock) void program_seg_kernel(Cols c, int64_t nve
                     for (int k = 0; k < V; k++) r[k].c[col] = t[k];
                 }
             }
+            if constexpr (sizeof...(CODES) > 0) {
+                bool sel[V];
+#pragma unroll
+                for (int k = 0; k < V; k++) sel[k] = true;
+                int i = 0;
+                ((exec_fixed<CODES, V, NT>(pg.op[i].flags, &s_par[sb][i][0], pg.op[i].aux, vv, r, sel), i++), ...);
+            } else
             for (int i = 0; i < pg.nops; i++) {
                 const ProgOp &o = pg.op[i];
                 bool sel[V];
@@ -627,6 +646,16 @@ int pxf_program_run_segments(const pxf_op_t *ops, int32_t nops, const double *se
     if (anymask) {
         if (nt) hipLaunchKernelGGL((program_seg_kernel<true, true>), grid, block, 0, s, c, nvec, pg, sg);
         else hipLaunchKernelGGL((program_seg_kernel<false, true>), grid, block, 0, s, c, nvec, pg, sg);
+    } else if (ChainSpoPair::matches(pg) && getenv("PXF_PROGRAM_NO_CHAIN") == nullptr) {
+        // the Arcus SPO stage (sector.py:574-612): rotate, spoPrimary, reflect, graze, spoSecondary, reflect, graze, move
+        if (nt)
+            hipLaunchKernelGGL((program_seg_kernel<true, false, true, PXF_OP_TRANSFORM, PXF_OP_SPOCONE, PXF_OP_REFLECT,
+                                                   PXF_OP_INDANGLE, PXF_OP_SPOCONE, PXF_OP_REFLECT, PXF_OP_INDANGLE,
+                                                   PXF_OP_TRANSFORM>), grid, block, 0, s, c, nvec, pg, sg);
+        else
+            hipLaunchKernelGGL((program_seg_kernel<false, false, true, PXF_OP_TRANSFORM, PXF_OP_SPOCONE, PXF_OP_REFLECT,
+                                                   PXF_OP_INDANGLE, PXF_OP_SPOCONE, PXF_OP_REFLECT, PXF_OP_INDANGLE,
+                                                   PXF_OP_TRANSFORM>), grid, block, 0, s, c, nvec, pg, sg);
     } else {
         bool hot = true;
         for (int i = 0; i < pg.nops; i++) hot &= (pg.op[i].flags & kHotOps) != 0;

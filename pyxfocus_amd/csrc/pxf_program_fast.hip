@@ -310,6 +310,34 @@ __device__ __forceinline__ void exec_fast_switch(int code, int flags, const doub
     }
 }
 
+// Straight-line form (see pxf_program.hip): the operation sequences of the BASELINE configs as compile-time lists,
+// the same fast_* bodies one after another with no dispatch.
+template <int CODE, int V, bool NT>
+__device__ __forceinline__ void exec_fast_fixed(int flags, const double *__restrict__ P, const double *aux, int64_t vv,
+                                                Ray (&r)[V])
+{
+    if constexpr (CODE == PXF_OP_TRANSFORM) fast_transform<V, false>(P, flags & 7, r);
+    else if constexpr (CODE == PXF_OP_ITRANSFORM) fast_transform<V, true>(P, flags & 7, r);
+    else if constexpr (CODE == PXF_OP_WOLTERPRIMARY) fast_wolterprimary<V>(P, r);
+    else if constexpr (CODE == PXF_OP_WOLTERSECONDARY) fast_woltersecondary<V>(P, r);
+    else if constexpr (CODE == PXF_OP_REFLECT) fast_reflect<V>(r);
+    else if constexpr (CODE == PXF_OP_FLAT) fast_flat<V>(r);
+    else if constexpr (CODE == PXF_OP_SPOCONE) fast_spocone<V>(P, r);
+    else if constexpr (CODE == PXF_OP_RADGRAT) fast_radgrat<V>(P, r);
+    else if constexpr (CODE == PXF_OP_INDANGLE) exec_fast_indangle<V, NT>(P, aux, vv, r);
+    else static_assert(CODE == PXF_OP_FLAT, "operation not available in a straight-line tolerance-mode program");
+}
+
+template <int... CODES>
+static bool fast_chain_matches(const Program &pg)
+{
+    constexpr int codes[] = {CODES...};
+    if (pg.nops != (int)sizeof...(CODES)) return false;
+    for (int i = 0; i < pg.nops; i++)
+        if (pg.op[i].code != codes[i] || pg.op[i].mask != nullptr) return false;
+    return true;
+}
+
 static bool fast_supported(const Program &pg)
 {
     for (int i = 0; i < pg.nops; i++) {
@@ -331,7 +359,7 @@ static bool fast_supported(const Program &pg)
     return true;
 }
 
-template <int V, bool NT>
+template <int V, bool NT, int... CODES>
 __global__ __launch_bounds__(kBlock) void program_fast_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -347,8 +375,13 @@ __global__ __launch_bounds__(kBlock) void program_fast_kernel(Cols c, int64_t fi
                 for (int k = 0; k < V; k++) r[k].c[col] = t[k];
             }
         }
-        for (int i = 0; i < pg.nops; i++)
-            exec_fast_flat<V, NT>(pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r);
+        if constexpr (sizeof...(CODES) > 0) {
+            int i = 0;
+            ((exec_fast_fixed<CODES, V, NT>(pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r), i++), ...);
+        } else {
+            for (int i = 0; i < pg.nops; i++)
+                exec_fast_flat<V, NT>(pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r);
+        }
 #pragma unroll
         for (int col = 0; col < 10; col++) {
             if (pg.store & B(col)) {
@@ -373,7 +406,7 @@ struct FastSegInfo {
     int nseg;
 };
 
-template <bool NT>
+template <bool NT, int... CODES>
 __global__ __launch_bounds__(kBlock) void program_fast_seg_kernel(Cols c, int64_t nvec, Program pg, FastSegInfo sg)
 {
     constexpr int V = 2;
@@ -404,8 +437,13 @@ __global__ __launch_bounds__(kBlock) void program_fast_seg_kernel(Cols c, int64_
                     for (int k = 0; k < V; k++) r[k].c[col] = t[k];
                 }
             }
-            for (int i = 0; i < pg.nops; i++)
-                exec_fast_switch<V, NT>(pg.op[i].code, pg.op[i].flags, &s_par[sb][i][0], pg.op[i].aux, vv, r);
+            if constexpr (sizeof...(CODES) > 0) {
+                int i = 0;
+                ((exec_fast_fixed<CODES, V, NT>(pg.op[i].flags, &s_par[sb][i][0], pg.op[i].aux, vv, r), i++), ...);
+            } else {
+                for (int i = 0; i < pg.nops; i++)
+                    exec_fast_switch<V, NT>(pg.op[i].code, pg.op[i].flags, &s_par[sb][i][0], pg.op[i].aux, vv, r);
+            }
 #pragma unroll
             for (int col = 0; col < 10; col++) {
                 if (pg.store & B(col)) {
@@ -452,16 +490,27 @@ int pxf_program_run_fast(const pxf_op_t *ops, int32_t nops, double *const *cols,
     hipStream_t s = (hipStream_t)stream;
     const bool nt = use_nt(num);
     const int64_t nvec2 = aligned ? num / 2 : 0;
-    if (nvec2 > 0) {
-        if (nt) hipLaunchKernelGGL((program_fast_kernel<2, true>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);
-        else hipLaunchKernelGGL((program_fast_kernel<2, false>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);
-    }
-    const int64_t done = nvec2 * 2;
-    if (done < num) {
-        const int64_t rest = num - done;
-        if (nt) hipLaunchKernelGGL((program_fast_kernel<1, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pg);
-        else hipLaunchKernelGGL((program_fast_kernel<1, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pg);
-    }
+    const int64_t done = nvec2 * 2, rest = num - done;
+    static const bool no_chain = getenv("PXF_PROGRAM_NO_CHAIN") != nullptr;   // dev knob (A/B against the interpreter)
+#define PXF_FAST_LAUNCH(...)                                                                                              \
+    do {                                                                                                                  \
+        if (nvec2 > 0) {                                                                                                  \
+            if (nt) hipLaunchKernelGGL((program_fast_kernel<2, true __VA_ARGS__>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg); \
+            else hipLaunchKernelGGL((program_fast_kernel<2, false __VA_ARGS__>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);  \
+        }                                                                                                                 \
+        if (rest > 0) {                                                                                                   \
+            if (nt) hipLaunchKernelGGL((program_fast_kernel<1, true __VA_ARGS__>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pg); \
+            else hipLaunchKernelGGL((program_fast_kernel<1, false __VA_ARGS__>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pg);  \
+        }                                                                                                                 \
+    } while (0)
+#define PXF_C2 PXF_OP_TRANSFORM, PXF_OP_WOLTERPRIMARY, PXF_OP_REFLECT, PXF_OP_WOLTERSECONDARY, PXF_OP_REFLECT, PXF_OP_FLAT
+#define PXF_GR PXF_OP_TRANSFORM, PXF_OP_FLAT, PXF_OP_REFLECT, PXF_OP_RADGRAT, PXF_OP_ITRANSFORM, PXF_OP_FLAT
+    // (the two-bounce program alone is already HBM-bound under the flat-if interpreter, and measured 2.5 % FASTER
+    // there than as a straight line -- 2.11 vs 2.17 ms per 1e8 rays, tools/ab_programs.py -- so it keeps the interpreter)
+    if (!no_chain && fast_chain_matches<PXF_GR>(pg)) PXF_FAST_LAUNCH(, PXF_GR);
+    else if (!no_chain && fast_chain_matches<PXF_C2, PXF_GR>(pg)) PXF_FAST_LAUNCH(, PXF_C2, PXF_GR);
+    else PXF_FAST_LAUNCH();
+#undef PXF_FAST_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }
@@ -492,8 +541,14 @@ int pxf_program_run_segments_fast(const pxf_op_t *ops, int32_t nops, const doubl
     const int64_t nvec = num / 2;
     FastSegInfo sg{seg_params_dev, rays_per_seg, nseg};
     const dim3 grid(grid_for(nvec)), block(kBlock);
-    if (use_nt(num)) hipLaunchKernelGGL((program_fast_seg_kernel<true>), grid, block, 0, s, c, nvec, pg, sg);
-    else hipLaunchKernelGGL((program_fast_seg_kernel<false>), grid, block, 0, s, c, nvec, pg, sg);
+#define PXF_SPO PXF_OP_TRANSFORM, PXF_OP_SPOCONE, PXF_OP_REFLECT, PXF_OP_INDANGLE, PXF_OP_SPOCONE, PXF_OP_REFLECT, PXF_OP_INDANGLE, PXF_OP_TRANSFORM
+    if (getenv("PXF_PROGRAM_NO_CHAIN") == nullptr && fast_chain_matches<PXF_SPO>(pg)) {   // the Arcus SPO pair per shell
+        if (use_nt(num)) hipLaunchKernelGGL((program_fast_seg_kernel<true, PXF_SPO>), grid, block, 0, s, c, nvec, pg, sg);
+        else hipLaunchKernelGGL((program_fast_seg_kernel<false, PXF_SPO>), grid, block, 0, s, c, nvec, pg, sg);
+    } else {
+        if (use_nt(num)) hipLaunchKernelGGL((program_fast_seg_kernel<true>), grid, block, 0, s, c, nvec, pg, sg);
+        else hipLaunchKernelGGL((program_fast_seg_kernel<false>), grid, block, 0, s, c, nvec, pg, sg);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
 }
