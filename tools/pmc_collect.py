@@ -73,6 +73,8 @@ def op_name(kernel):
             j += 1
         return k[i:j].strip()
     k = re.sub(r"^void\s+", "", k)
+    if k.startswith("_ZN3pxf19program_fast_kernel"):     # (an empty template pack the profiler's demangler gives up on)
+        return "program_fast_kernel<interpreter>"
     k = k.split("(")[0]
     return k.replace("pxf::", "")[:70]
 
@@ -185,7 +187,7 @@ def write_tables(tag, target, ks, rays, note, launch_bytes):
             alg.setdefault(op, 120)                 # the L-L pair of tools/bench_ops.py: 6 columns in, 9 out
         if op == "program_mirror_kernel<0, true>":
             alg.setdefault(op, 144)                 # the W-S pair: 9 in (a failed W-S ray keeps its normal), 9 out
-        if op.split("<")[0] in ("program_kernel", "program_zern_kernel", "program_fast_kernel") and target not in ("ops", "config5"):
+        if op.split("<")[0] in ("program_kernel", "program_zern_kernel", "program_fast_kernel", "program_chain_kernel") and target not in ("ops", "config5"):
             alg.setdefault(op, 120)                 # the configs' programs: 6 columns in, 9 out
         if op.split("<")[0] in ("program_seg_kernel", "program_fast_seg_kernel"):
             alg.setdefault(op, 160)                 # SPO pair: 9 in (a cone miss keeps position+normal), 9 out, 2 angle columns
@@ -287,5 +289,22 @@ def main():
         json.dump(flops, open(os.path.join(OUTDIR, "pmc_flops.json"), "w"), indent=1)
 
 
+def retable(tag):
+    """Rebuild profiles/<tag>_*_kernels.md from the committed JSONs (after a change to the table logic; no GPU)."""
+    global OUTDIR
+    from tools import workloads as wl
+    OUTDIR = os.path.join(ROOT, "profiles")
+    lb = {"config2": wl.CONFIG2, "config3": wl.CONFIG3, "config4": wl.CONFIG4}
+    for f in sorted(glob.glob(os.path.join(OUTDIR, tag + "_*_kernels.json"))):
+        d = json.load(open(f))
+        ks = {}
+        for op, e in d["kernels"].items():
+            ks[op_name(e["kernel"]) if op.startswith("_ZN") else op] = e
+        write_tables(tag, d["target"], ks, d["rays_per_launch"], d["note"], lb.get(d["target"], []))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--retable":
+        retable(sys.argv[2])
+    else:
+        main()
