@@ -118,8 +118,11 @@ def main():
 
     ops = [
         # name, input builder, call, algorithmic B/ray
-        ("transform", wolter_in, lambda r: tran.transform(r, .1, -.2, 3., 1e-3, -2e-3, .5), 144),
-        ("itransform", wolter_in, lambda r: tran.itransform(r, .1, -.2, 3., 1e-3, -2e-3, .5), 144),
+        # (a general frame change of a bundle whose normals are set: all nine columns change and are rewritten; a
+        #  pure translation rewrites one -- TransformOp stores only what changed)
+        ("transform", normal_beam, lambda r: tran.transform(r, .1, -.2, 3., 1e-3, -2e-3, .5), 144),
+        ("itransform", normal_beam, lambda r: tran.itransform(r, .1, -.2, 3., 1e-3, -2e-3, .5), 144),
+        ("transform (pure translation along z)", normal_beam, lambda r: tran.transform(r, 0, 0, -100., 0, 0, 0), 80),
         ("flat", beam, lambda r: surf.flat(r), 96),
         ("flatopd", beam, lambda r: surf.flat(r, nr=1.), 112),
         ("reflect", normal_beam, lambda r: tran.reflect(r), 72),
