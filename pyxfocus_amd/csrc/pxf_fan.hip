@@ -69,11 +69,7 @@ __device__ __forceinline__ bool fan_in_range(const double *c, const FanGeom &g)
 // component that is not -0, not infinite and not NaN (a -0 can come back +0, a NaN or infinity contaminates its
 // neighbours: those rays take the full arithmetic).  `v_cmp_class_f64` tests all three conditions in one
 // instruction; 15 class tests replace 39 multiplies and adds per round.
-__device__ __forceinline__ bool fan_special(double v)
-{
-    // sNaN | qNaN | -inf | -0 | +inf
-    return __builtin_amdgcn_class(v, 0x001 | 0x002 | 0x004 | 0x020 | 0x200);
-}
+__device__ __forceinline__ bool fan_special(double v) { return special_value(v); }   // pxf_ops_transforms.h
 // +0 translation, (cos, sin) = (1, +0) about y and z -- compared as bit patterns (a -0 sine multiplies differently)
 __device__ __forceinline__ bool fan_x_only(const TransformOp<false> &rot)
 {

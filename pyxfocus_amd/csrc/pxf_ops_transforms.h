@@ -32,6 +32,21 @@ __device__ __forceinline__ void rotv(double &x, double &y, double &z, double c, 
     }
 }
 
+// A rotation by an angle of zero -- (cos, sin) = (1, +-0) -- is the identity for every component that is not -0,
+// not infinite and not NaN: 1*x - 0*y = x - (+-0) = x, and +0 stays +0.  (A -0 can come back +0 and a NaN or infinity
+// reaches its neighbours: those vectors take the full arithmetic.)  `v_cmp_class_f64` tests all of that in one
+// instruction, so a vector whose three rotations are all by zero costs three class tests instead of 18 multiplies
+// and adds -- it matters in the VALU-bound fused programs, whose leading frame change is usually a pure translation.
+__device__ __forceinline__ bool special_value(double v)
+{
+    return __builtin_amdgcn_class(v, 0x001 | 0x002 | 0x004 | 0x020 | 0x200);   // sNaN | qNaN | -inf | -0 | +inf
+}
+__device__ __forceinline__ bool plain3(double a, double b, double c)
+{
+    return !((int)special_value(a) | (int)special_value(b) | (int)special_value(c));
+}
+__device__ __forceinline__ bool zero_angle(double c, double s) { return c == 1. && s == 0.; }
+
 // transform : transformationsf.f95:134-163 ; itransform : :168-201.   R 9 + W 9 = 144 B/ray
 template <bool INVERSE>
 struct TransformOp {
@@ -54,40 +69,45 @@ struct TransformOp {
             double before[9];
 #pragma unroll
             for (int j = 0; j < 9; j++) before[j] = c[X + j];
+            const bool norot = zero_angle(cx, sx) && zero_angle(cy, sy) && zero_angle(cz, sz);   // wave-uniform
             if (!INVERSE) {
                 if (gp) {
                     c[X] = c[X] + tx;
                     c[Y] = c[Y] + ty;
                     c[Z] = c[Z] + tz;
-                    rotv<1>(c[X], c[Y], c[Z], cx, sx);
-                    rotv<2>(c[X], c[Y], c[Z], cy, sy);
-                    rotv<3>(c[X], c[Y], c[Z], cz, sz);
+                    if (!(norot && plain3(c[X], c[Y], c[Z]))) {
+                        rotv<1>(c[X], c[Y], c[Z], cx, sx);
+                        rotv<2>(c[X], c[Y], c[Z], cy, sy);
+                        rotv<3>(c[X], c[Y], c[Z], cz, sz);
+                    }
                 }
-                if (gd) {
+                if (gd && !(norot && plain3(c[L], c[M], c[N]))) {
                     rotv<1>(c[L], c[M], c[N], cx, sx);
                     rotv<2>(c[L], c[M], c[N], cy, sy);
                     rotv<3>(c[L], c[M], c[N], cz, sz);
                 }
-                if (gn) {
+                if (gn && !(norot && plain3(c[UX], c[UY], c[UZ]))) {
                     rotv<1>(c[UX], c[UY], c[UZ], cx, sx);
                     rotv<2>(c[UX], c[UY], c[UZ], cy, sy);
                     rotv<3>(c[UX], c[UY], c[UZ], cz, sz);
                 }
             } else {
                 if (gp) {
-                    rotv<3>(c[X], c[Y], c[Z], cz, sz);
-                    rotv<2>(c[X], c[Y], c[Z], cy, sy);
-                    rotv<1>(c[X], c[Y], c[Z], cx, sx);
+                    if (!(norot && plain3(c[X], c[Y], c[Z]))) {
+                        rotv<3>(c[X], c[Y], c[Z], cz, sz);
+                        rotv<2>(c[X], c[Y], c[Z], cy, sy);
+                        rotv<1>(c[X], c[Y], c[Z], cx, sx);
+                    }
                     c[X] = c[X] - tx;
                     c[Y] = c[Y] - ty;
                     c[Z] = c[Z] - tz;
                 }
-                if (gd) {
+                if (gd && !(norot && plain3(c[L], c[M], c[N]))) {
                     rotv<3>(c[L], c[M], c[N], cz, sz);
                     rotv<2>(c[L], c[M], c[N], cy, sy);
                     rotv<1>(c[L], c[M], c[N], cx, sx);
                 }
-                if (gn) {
+                if (gn && !(norot && plain3(c[UX], c[UY], c[UZ]))) {
                     rotv<3>(c[UX], c[UY], c[UZ], cz, sz);
                     rotv<2>(c[UX], c[UY], c[UZ], cy, sy);
                     rotv<1>(c[UX], c[UY], c[UZ], cx, sx);

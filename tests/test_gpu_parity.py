@@ -599,3 +599,41 @@ def test_legsurf_and_conicplus_parameter_ranges(port):
             assert bits_equal(got[k], want[k]).all(), ("conicplus", npc, k)
     with pytest.raises(_lib.PxfError):
         call_gpu(fn, to_dev(cols), tuple(args[:2]) + (np.ones(17) * 1e-30,))
+
+
+@pytest.mark.parametrize("fn", ["transformationsf.transform", "transformationsf.itransform"])
+def test_zero_angle_frame_changes_special_values_bitwise(port, fn):
+    """A frame change with zero angles skips its rotations for every vector made of ordinary numbers (and stores only
+    what changed); a vector holding a -0, an infinity or a NaN must still go through the reference's arithmetic
+    (1*x - 0*y ...: the -0 may come back +0, the NaN reaches its neighbours).  Pure translations, +0 and -0 angles,
+    rotations about one axis only -- bundles salted with special values in every column -- stand-alone and inside a
+    fused program, bit for bit against the oracle."""
+    import pyxfocus_amd as pxf
+    from pyxfocus_amd import native
+    rng = np.random.default_rng(5)
+    n = 4096
+    cols = {k: rng.normal(0., 1., n) for k in ALLCOLS}
+    specials = [0., -0., np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e300, -1e-300]
+    for j, k in enumerate(ALLCOLS[1:]):
+        idx = rng.choice(n, 400, replace=False)
+        cols[k][idx] = rng.choice(specials, 400)
+        cols[k][j::97] = 0.                                    # plenty of +0 (the normals of a fresh source)
+    nine = ALLCOLS[1:]
+    for args in ((0., 0., -8600., 0., 0., 0.), (1.5, -2.5, 0., -0., 0., -0.), (0., 0., 0., 0., 0., 0.),
+                 (0., 0., 3., .01, 0., 0.), (0., 0., 0., 0., 0., .3), (-0., 0., 7., 0., -.2, 0.)):
+        want = {k: v.copy() for k, v in cols.items()}
+        getattr(port.transformationsf, fn.split(".")[1])(*[want[k] for k in nine], *args)
+        for fused in (False, True):
+            t = to_dev(cols)
+            if fused:
+                with pxf.fused():
+                    getattr(native.transformationsf, fn.split(".")[1])(*[t[k] for k in nine], *args)
+                    native.transformationsf.reflect(*[t[k] for k in "l m n ux uy uz".split()])
+                w2 = {k: v.copy() for k, v in want.items()}
+                port.transformationsf.reflect(*[w2[k] for k in "l m n ux uy uz".split()])
+            else:
+                getattr(native.transformationsf, fn.split(".")[1])(*[t[k] for k in nine], *args)
+                w2 = want
+            got = to_host(t)
+            for k in ALLCOLS:
+                assert bits_equal(got[k], w2[k]).all(), (fn, args, fused, k, int((~bits_equal(got[k], w2[k])).sum()))
