@@ -244,7 +244,10 @@ int pxf_zernphase(double *opd, const double *x, const double *y, double *l, doub
 
 /* transform(x,...,uz,num,tx,ty,tz,rx,ry,rz)  transformationsf.f95:134-163
  * p += t, then Rx(rx) Ry(ry) Rz(rz) on position, direction and normal.  (The Python wrapper
- * negates all six parameters before this call, transformations.py:29.) */
+ * negates all six parameters before this call, transformations.py:29.)  Every column is READ and every number
+ * goes through the reference's arithmetic; a column is REWRITTEN only where a value changed (bit compare), so a
+ * pure translation along one axis moves 72 + 8 B per ray instead of 144 -- same results, NaN / -0 propagation
+ * through the zero-angle rotations included. */
 int pxf_transform(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
                   double *uy, double *uz, int64_t num, double tx, double ty, double tz, double rx,
                   double ry, double rz, const uint8_t *mask, pxf_stream_t stream);
