@@ -265,7 +265,9 @@ def main():
         print("== target %s" % t, flush=True)
         out = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (a.tag, t))
         ks = collect(t, cmd, out)
-        write_tables(a.tag, t, ks, rays, note + "  Commit %s, csrc %s." % (a.commit, bench.csrc_hash()), launches)
+        shown = " ".join(os.path.relpath(c, ROOT) if c.startswith(ROOT) else c for c in cmd)
+        write_tables(a.tag, t, ks, rays, note + "  Commit %s, csrc %s.  Command: `rocprofv3 --kernel-trace --stats -- %s` "
+                     "(and the same under `--pmc ...`)." % (a.commit, bench.csrc_hash(), shown), launches)
         shared = defaultdict(list)
         for lname, nb in launches:
             shared[LAUNCH_KERNEL.get(lname)].append(nb)
