@@ -157,7 +157,10 @@ __global__ __launch_bounds__(kRecMaxBlock) void reconstruct_kernel(double *xang,
                 const double pn = pco + w * ((psum + bk) / goodpix - pco);  // :98
                 pc[o] = pn;
                 cnt += 1;
-                const double df = pn - phase[o];
+                // :102 (phasec - phase)**2: `phase` holds the previous sweep's value of this cell, which is what
+                // pc[o] held until this very update (phase = phasec after every sweep, :114) -- so the old value
+                // is already in a register and `phase` itself is only written once, when the loop ends
+                const double df = pn - pco;
                 acc += df * df;
             }
             __syncthreads();
@@ -181,7 +184,6 @@ __global__ __launch_bounds__(kRecMaxBlock) void reconstruct_kernel(double *xang,
             }
             s_rms = sqrt(t / (double)c);  // :112 (0/0 -> NaN -> never "< criteria", as in the reference)
         }
-        for (int b = tid; b < nb; b += nthr) phase[b] = pc[b];  // :114
         __syncthreads();
         sweeps++;
         if (s_rms < criteria) break;
@@ -189,8 +191,11 @@ __global__ __launch_bounds__(kRecMaxBlock) void reconstruct_kernel(double *xang,
         if (counter > maxiter) break;
         __syncthreads();  // s_rms is rewritten next sweep only after every thread has read it
     }
-    if (PLDS)
-        for (int b = tid; b < nb; b += nthr) phasec[b] = pc[b];
+    for (int b = tid; b < nb; b += nthr) {  // :114 phase = phasec, once: nothing reads `phase` inside the loop
+        const double v = pc[b];
+        phase[b] = v;
+        if (PLDS) phasec[b] = v;
+    }
     if (tid == 0 && sweeps_out) *sweeps_out = sweeps;
 }
 
