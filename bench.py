@@ -63,13 +63,30 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+RAY_KERNEL_SOURCES = ("Makefile", "pxf_core.hip", "pxf_kernel.h", "pxf_ops_surfaces.h", "pxf_ops_transforms.h",
+                      "pxf_ops_zernike.h", "pxf_surfaces.hip", "pxf_transforms.hip", "pxf_zernike.hip")
+
+
+def ray_kernels_hash():
+    """Identity of the sources the per-call ray kernels of configs 2-4 are built from (the kernels whose PMC traffic
+    and flop counts the bench line quotes): a change elsewhere in csrc/ (wavefront, fan, select ...) does not make
+    those figures stale."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pyxfocus_amd", "csrc")
+    for f in RAY_KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_entry(fname, key, rays):
     """A committed PMC figure (tools/pmc_collect.py) for `key` -- only if it was captured from THESE
     kernel sources and at this launch size; otherwise None (never a stale number)."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", fname)))
         ent = tj["kernels"].get(key)
-        if ent and tj.get("csrc_hash") == csrc_hash() and int(ent.get("rays", 0)) == int(rays):
+        fresh = tj.get("csrc_hash") == csrc_hash() or tj.get("ray_kernels_hash") == ray_kernels_hash()
+        if ent and fresh and int(ent.get("rays", 0)) == int(rays):
             return dict(ent, source=tj.get("source"), commit=tj.get("commit"))
     except Exception:
         pass

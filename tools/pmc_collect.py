@@ -249,10 +249,10 @@ def main():
                 int(1e8), [], "Legendre-Legendre / Wolter-Schwarzschild / woltersine / Zernike kernels one by one "
                 "(tools/bench_ops.py, 1e8 rays)."),
     }
-    traffic = {"csrc_hash": bench.csrc_hash(), "commit": a.commit, "source": "tools/pmc_collect.py --tag " + a.tag,
-               "kernels": {}}
-    flops = {"csrc_hash": bench.csrc_hash(), "commit": a.commit, "source": "tools/pmc_collect.py --tag " + a.tag,
-             "kernels": {}}
+    traffic = {"csrc_hash": bench.csrc_hash(), "ray_kernels_hash": bench.ray_kernels_hash(), "commit": a.commit,
+               "source": "tools/pmc_collect.py --tag " + a.tag, "kernels": {}}
+    flops = {"csrc_hash": bench.csrc_hash(), "ray_kernels_hash": bench.ray_kernels_hash(), "commit": a.commit,
+             "source": "tools/pmc_collect.py --tag " + a.tag, "kernels": {}}
     for fn, blob in (("pmc_traffic.json", traffic), ("pmc_flops.json", flops)):      # keep entries of targets not re-run
         try:
             old = json.load(open(os.path.join(ROOT, "profiles", fn)))
