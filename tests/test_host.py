@@ -5,6 +5,7 @@
 * sources.py numpy path, coords bookkeeping and matrix helpers against vectors captured from the
   reference's own sources.py / transformations.py (tests/golden).
 """
+import ctypes as C
 import os
 import re
 import subprocess
@@ -199,6 +200,45 @@ def test_program_planner_liveness():
     from pyxfocus_amd import _lib
     with _pt.raises(_lib.PxfError):
         f.plan([mk(99)])
+    # programs that hold mirrors (PXF_OP_WSPRIMARY = 26 ...): a W-S trace may give up and keep the normal -> the
+    # normal is a conditional write and is loaded; woltersine / the L-L kinds define it (their host tables come in `aux`)
+    assert f.plan([mk(8, 0, 0, 1, 0, 0, 0), mk(26, .0065, 8400., 1.), mk(10), mk(1)]) == (pos | dirs | nrm, pos | dirs | nrm, 0)
+    assert f.plan([mk(8, 0, 0, 1, 0, 0, 0), mk(30, 220., 8400., 1e-4, .1), mk(10), mk(1)]) == (pos | dirs, pos | dirs | nrm, 1)
+    la = f.PxfLLArgs()
+    ll = mk(31, 220., 8400., 8500., 8400., .4)
+    ll.aux = C.addressof(la)
+    assert f.plan([ll, mk(10)]) == (pos | dirs, pos | dirs | nrm, 0)
+    with _pt.raises(_lib.PxfError):                      # an L-L operation without its coefficient list
+        f.plan([mk(31, 220., 8400., 8500., 8400., .4)])
+    with _pt.raises(_lib.PxfError):                      # more operations than a mirror program may hold
+        f.plan([mk(8, 0, 0, 1, 0, 0, 0)] * 12 + [mk(26, .0065, 8400., 1.)])
+    za = f.PxfZernArgs()
+    zz = mk(23, 50.)
+    zz.aux = C.addressof(za)
+    with _pt.raises(_lib.PxfError):                      # a Zernike trace and a mirror never share a program
+        f.plan([zz, mk(26, .0065, 8400., 1.)])
+
+
+def test_fused_recorder_rules_for_mirror_programs():
+    """Host logic of pyxfocus_amd.fused() around mirrors (no GPU: the recorder only): which calls may join a
+    pending program, the 12-operation limit, the Legendre-Legendre coefficient pool."""
+    from pyxfocus_amd import _fused as f
+    rec = f._Recorder()
+    assert rec._ll_pool_fits([(10, 10), (10, 10)])           # two 11 x 11 sets: 2 x 12 x 12 = 288 cells
+    assert not rec._ll_pool_fits([(12, 11), (12, 11)])       # 2 x 14 x 12 > 288
+    assert not rec._ll_pool_fits([(4, 12)])                  # azimuthal order 12: stand-alone kernel
+    assert not rec._ll_pool_fits([(16, 3)])                  # 18 padded rows > 16
+    assert rec._ll_pool_fits([(2, 2), (14, 7)])              # mixed shapes share the larger column count
+    assert rec._mirror_may_join(None)
+    assert not rec._mirror_may_join(object())                # ind= masks run as separate launches
+    op = f.PxfOp()
+    op.code = 3                                              # a conic is not a mirror-program companion
+    rec.ops.append(op)
+    assert not rec._mirror_may_join(None)
+    rec.ops[0].code = 10
+    assert rec._mirror_may_join(None)
+    rec.ops.extend([rec.ops[0]] * 11)
+    assert not rec._mirror_may_join(None)                    # 12 operations already
 
 
 def test_design_helpers_match_reference_conicsolve(golden):
