@@ -22,6 +22,16 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+/* cos(theta), sin(theta) of ONE angle as the reference BINARY forms them: flang (like gfortran / gcc) merges the pair
+ * of calls in rotatevector (transformationsf.f95:10-22), spoCone (woltsurf.f95:605-606) ... into one call of the C
+ * library's `sincos`, which in glibc 2.35 is the non-FMA build of the algorithm and differs from sin() / cos() in
+ * the last bit for about one argument in a thousand.  The restatement calls it EXPLICITLY, so that it does not
+ * depend on what this file's compiler happens to merge: round 2 found orc_itransform's `cos(-rx), sin(-rx)` folded to
+ * cos(rx), -sin(rx) -- two separate calls, no sincos -- and therefore an ulp off the reference for such angles
+ * (tests/test_oracle.py::test_port_matches_reference_where_sincos_differs). */
+extern void sincos(double, double *, double *);
+static inline void ref_cos_sin(double theta, double *c, double *s) { sincos(theta, s, c); }
+
 /* Fortran single-precision literals widened to double. */
 #define TOL_1EM8 ((double)1.e-8f)   /* woltsurf.f95:30,136  "1.e-8"  */
 #define TOL_1EM10 ((double)1.e-10f) /* woltsurf.f95:83, zernsurf.f95:31 "1.e-10" */
@@ -425,7 +435,10 @@ void orc_transform(double *x, double *y, double *z, double *l, double *m, double
                    double *uy, double *uz, int64_t num, double tx, double ty, double tz, double rx,
                    double ry, double rz)
 {
-    const double cx = cos(rx), sx = sin(rx), cy = cos(ry), sy = sin(ry), cz = cos(rz), sz = sin(rz);
+    double cx, sx, cy, sy, cz, sz;
+    ref_cos_sin(rx, &cx, &sx);
+    ref_cos_sin(ry, &cy, &sy);
+    ref_cos_sin(rz, &cz, &sz);
 #pragma omp parallel for
     for (int64_t i = 0; i < num; i++) {
         x[i] = x[i] + tx;
@@ -448,7 +461,10 @@ void orc_itransform(double *x, double *y, double *z, double *l, double *m, doubl
                     double *uy, double *uz, int64_t num, double tx, double ty, double tz, double rx,
                     double ry, double rz)
 {
-    const double cx = cos(-rx), sx = sin(-rx), cy = cos(-ry), sy = sin(-ry), cz = cos(-rz), sz = sin(-rz);
+    double cx, sx, cy, sy, cz, sz;       /* tmp = -rz ...: rotatevector(..., tmp, axis) (:180-191) */
+    ref_cos_sin(-rx, &cx, &sx);
+    ref_cos_sin(-ry, &cy, &sy);
+    ref_cos_sin(-rz, &cz, &sz);
 #pragma omp parallel for
     for (int64_t i = 0; i < num; i++) {
         rotatevector(&x[i], &y[i], &z[i], cz, sz, 3);
@@ -523,7 +539,9 @@ void orc_radgratw(const double *x, const double *y, double *l, double *m, double
 void orc_spocone(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,
                  double *uy, double *uz, int64_t num, double R0, double tg)
 {
-    const double sl = tan(tg), ctg = cos(tg), stg = sin(tg);
+    const double sl = tan(tg);
+    double ctg, stg;
+    ref_cos_sin(tg, &ctg, &stg);
 #pragma omp parallel for
     for (int64_t i = 0; i < num; i++) {
         double A = n[i] * n[i] * (sl * sl) - m[i] * m[i] - l[i] * l[i];

@@ -18,6 +18,7 @@
 //    add/mul/div/sqrt the results are then bit-identical to it.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/pxf.h"
@@ -189,6 +190,14 @@ __global__ __launch_bounds__(kBlock, min_waves<Op>::value) void ray_kernel(Cols 
 }
 
 // ---- host side ---------------------------------------------------------------------------
+// cos / sin of a host-side angle exactly as the reference BINARY forms them: both compilers (flang for the reference,
+// gcc for the oracle) merge the `cos(theta)`, `sin(theta)` of rotatevector (transformationsf.f95:10-22) and of spoCone
+// (woltsurf.f95:605-606) into ONE call of the C library's `sincos` -- which in glibc is built without FMA and differs
+// from `sin()` / `cos()` (the FMA builds) in the last bit for about one argument in a thousand.  Calling sin() and
+// cos() made a frame change with such an angle differ from the reference by an ulp in a fifth of the rays (found by a
+// 600-seed soak of tests/test_gpu_fuzz.py; angle -0.1610095633704616).  Hence sincos().
+inline void host_sincos(double a, double &c, double &s) { ::sincos(a, &s, &c); }
+
 extern thread_local int g_last_hip_error;
 int device_cus();
 int blocks_per_cu_cap();

@@ -291,14 +291,10 @@ inline void trig6(double rx, double ry, double rz, bool inverse, double (&cs)[6]
         ry = -ry;
         rz = -rz;
     }
-    cs[0] = cos(rx);
-    cs[1] = sin(rx);
-    cs[2] = cos(ry);
-    cs[3] = sin(ry);
-    cs[4] = cos(rz);
-    cs[5] = sin(rz);
+    host_sincos(rx, cs[0], cs[1]);
+    host_sincos(ry, cs[2], cs[3]);
+    host_sincos(rz, cs[4], cs[5]);
 }
-
 
 inline void radgrat_consts(double &S, double &C)
 {

@@ -364,8 +364,7 @@ int plan_program(const pxf_op_t *ops, int32_t nops, Program &pg, int *dropped, i
             case PXF_OP_SPOCONE:
                 o.p[0] = u.a[0];
                 o.p[1] = tan(u.a[1]);
-                o.p[2] = cos(u.a[1]);
-                o.p[3] = sin(u.a[1]);
+                host_sincos(u.a[1], o.p[2], o.p[3]);   // the reference binary: one sincos (pxf_ops_transforms.h)
                 add(POS | DIR, 0, POS | DIR | NRM, 0);  // miss: lmn zeroed, xyz/u kept
                 break;
             case PXF_OP_SPHERE:

@@ -98,8 +98,10 @@ int pxf_woltersecondary(double *x, double *y, double *z, const double *l, const 
 int pxf_spocone(double *x, double *y, double *z, double *l, double *m, double *n, double *ux, double *uy,
                 double *uz, int64_t num, double R0, double tg, const uint8_t *mask, pxf_stream_t stream)
 {
+    double ctg, stg;
+    host_sincos(tg, ctg, stg);   // woltsurf.f95:591-638 compiles to one `sincos` + one `tan` (pxf_ops_transforms.h)
     return launch_rays(cols9(nullptr, x, y, z, l, m, n, ux, uy, uz), num, mask, stream,
-                       SpoConeOp{R0, tan(tg), cos(tg), sin(tg)});
+                       SpoConeOp{R0, tan(tg), ctg, stg});
 }
 
 int pxf_tracesphere(double *x, double *y, double *z, double *l, double *m, double *n, double *ux,

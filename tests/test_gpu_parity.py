@@ -637,3 +637,47 @@ def test_zero_angle_frame_changes_special_values_bitwise(port, fn):
             got = to_host(t)
             for k in ALLCOLS:
                 assert bits_equal(got[k], w2[k]).all(), (fn, args, fused, k, int((~bits_equal(got[k], w2[k])).sum()))
+
+
+def test_frame_angles_where_libm_sincos_differs_from_sin_and_cos(port):
+    """The reference binary forms the cos / sin of a frame angle with ONE call of the C library's `sincos` (both
+    flang and gcc merge the pair), and glibc's sincos -- built without FMA -- differs from its sin() / cos() in the
+    last bit for about one argument in a thousand.  The host side of the kernels therefore calls sincos too
+    (pxf_kernel.h: host_sincos).  Regression (found by a 600-seed soak of the fuzz test): frame changes and SPO cones
+    at angles picked so that sincos != (sin, cos) -- bit for bit against the oracle."""
+    import ctypes as C
+    from pyxfocus_amd import native
+    libm = C.CDLL("libm.so.6")
+    for f in (libm.sin, libm.cos):
+        f.restype, f.argtypes = C.c_double, [C.c_double]
+    libm.sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(251)
+    odd = [-0.1610095633704616]                       # the soak's angle
+    while len(odd) < 12:
+        a = float(rng.uniform(-3.1, 3.1)) if len(odd) % 2 else float(rng.uniform(-.02, .02))
+        s, c = C.c_double(), C.c_double()
+        libm.sincos(a, C.byref(s), C.byref(c))
+        if s.value != libm.sin(a) or c.value != libm.cos(a):
+            odd.append(a)
+    base = {name: (fn, cols, args) for name, fn, cols, args in cases.cases(num=2048, seed=9)}
+    nine = ALLCOLS[1:]
+    for i in range(0, 12, 3):
+        ang = odd[i:i + 3]
+        for fn in ("transform", "itransform"):
+            cols = base["transform_general"][1]
+            want = {k: v.copy() for k, v in cols.items()}
+            getattr(port.transformationsf, fn)(*[want[k] for k in nine], 1.5, -2.5, 30., *ang)
+            t = to_dev(cols)
+            getattr(native.transformationsf, fn)(*[t[k] for k in nine], 1.5, -2.5, 30., *ang)
+            got = to_host(t)
+            for k in ALLCOLS:
+                assert bits_equal(got[k], want[k]).all(), (fn, ang, k)
+    fn, cols, args = base["spocone_prim"]
+    for tg in [a for a in odd if abs(a) < .03][:3] + [abs(odd[1]) % .02 + .002]:
+        want = {k: v.copy() for k, v in cols.items()}
+        port.woltsurf.spocone(*[want[k] for k in nine], args[0], tg)
+        t = to_dev(cols)
+        native.woltsurf.spocone(*[t[k] for k in nine], args[0], tg)
+        got = to_host(t)
+        for k in ALLCOLS:
+            assert bits_equal(got[k], want[k]).all(), ("spocone", tg, k)
