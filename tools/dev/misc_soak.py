@@ -1,0 +1,80 @@
+"""dev: randomised sizes / shapes through vignette (stable compaction), the focal-plane order statistics and the
+Legendre-Legendre kernels, GPU vs NumPy / the oracle.  usage: misc_soak.py [iterations] [seed]"""
+import math, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import api, cases
+from util import ALLCOLS, call_gpu, to_dev, to_host
+import pyxfocus_amd.analyses as anal, pyxfocus_amd.transformations as tran
+port = api.load_port()
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+
+
+def fail(*a):
+    global bad
+    bad += 1
+    print("MISMATCH", *a)
+
+
+for it in range(iters):
+    # ---- vignette: sizes around the tile / wave / block boundaries, random keep fractions ------------------------
+    n = int(rng.choice([1, 2, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 4096, 100_003, 1_000_001, int(rng.integers(1, 3_000_000))]))
+    keepf = float(rng.choice([0., 1., .5, .01, .99, rng.random()]))
+    cols = [torch.from_numpy(rng.normal(size=n)).cuda() for _ in range(10)]
+    mask = rng.random(n) < keepf
+    form = int(rng.integers(0, 3))
+    ind = [torch.from_numpy(mask).cuda(), np.where(mask)[0], np.where(mask)][form]
+    out = tran.vignette(cols, ind)
+    for k in range(10):
+        if not np.array_equal(out[k].cpu().numpy(), cols[k].cpu().numpy()[mask]):
+            fail("vignette", n, keepf, form, k)
+            break
+    # ---- order statistics: hpd / hpdY / weighted, random sizes, ties ------------------------------------------------
+    n = int(rng.choice([1, 2, 3, 1000, 1001, 65_536, 4_194_304 + int(rng.integers(0, 3)), int(rng.integers(2, 6_000_000))]))
+    x = rng.normal(0, 1, n) * float(rng.choice([1e-6, 1., 1e3])) + float(rng.choice([0., 5., -300.]))
+    y = rng.normal(0, 2, n)
+    if rng.random() < .3:
+        x = np.round(x, 1); y = np.round(y, 1)                          # heavy ties
+    rays = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(10)]
+    rays[1] = torch.from_numpy(x).cuda(); rays[2] = torch.from_numpy(y).cuda()
+    cx, cy = x.mean(), y.mean()
+    want = 2 * np.median(np.sqrt((x - cx) ** 2 + (y - cy) ** 2))
+    got = anal.hpd(rays)
+    if not abs(got - want) <= 1e-11 * max(1., abs(want)):
+        fail("hpd", n, got, want)
+    wantY = 2 * np.median(np.abs(y - cy))
+    gotY = anal.hpdY(rays)
+    if not abs(gotY - wantY) <= 1e-11 * max(1., abs(wantY)):
+        fail("hpdY", n, gotY, wantY)
+    if n >= 3:
+        w = rng.random(n) + .01
+        cxw, cyw = np.average(x, weights=w), np.average(y, weights=w)
+        r = np.sqrt((x - cxw) ** 2 + (y - cyw) ** 2)
+        o = np.argsort(r, kind="stable"); cdf = np.cumsum(w[o]); cdf = cdf / cdf.max()
+        wantw = r[o][np.argmin(np.abs(cdf - .75))] - r[o][np.argmin(np.abs(cdf - .25))]
+        gotw = anal.hpd(rays, weights=torch.from_numpy(w).cuda())
+        if not abs(gotw - wantw) <= 1e-9 * max(1., abs(wantw)):
+            fail("hpd weighted", n, gotw, wantw)
+    # ---- Legendre-Legendre: random coefficient shapes, amplitudes, extents ----------------------------------------------
+    base = {name: (fn, c, a) for name, fn, c, a in cases.cases(num=600, seed=int(rng.integers(1, 10_000)))
+            if name in ("wolterprimll", "woltersecll", "ellipsoidwoltll")}
+    ka, kt = int(rng.integers(0, 16)), int(rng.integers(0, 20))
+    while (ka + 1) * (kt + 1) > 256:                                    # the entry's documented limit
+        ka -= 1
+    ax, az = np.meshgrid(np.arange(ka + 1), np.arange(kt + 1), indexing="ij")
+    keep = rng.random(ax.size) < rng.choice([.3, .8, 1.])
+    keep[-1] = True
+    coeff = (rng.normal(0., 2e-5, ax.size) / (1 + ax.flatten() + az.flatten()))[keep]
+    axk, azk = ax.flatten()[keep].astype(np.int32), az.flatten()[keep].astype(np.int32)
+    for name, (fn, c, args) in base.items():
+        a = tuple(args[:-3]) + (coeff, axk, azk)
+        want = {k: v.copy() for k, v in c.items()}
+        cases.call(port, fn, want, a)
+        t = to_dev(c); call_gpu(fn, t, a); got = to_host(t)
+        d = np.sqrt(sum((got[k] - want[k]) ** 2 for k in "xyz"))
+        if not (np.nanmax(d) <= 1e-10 and np.array_equal(np.isnan(got["x"]), np.isnan(want["x"]))):
+            fail(name, "ka", ka, "kt", kt, "max %.2e" % np.nanmax(d))
+print("misc soak: %d iterations, %d mismatches" % (iters, bad))
