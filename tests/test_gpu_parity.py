@@ -478,7 +478,7 @@ def test_legendre_legendre_order_ranges(port, kt, ka):
     the reference evaluates P_n by an explicit factorial sum (specialFunctions.f95:337-388) that loses digits
     with n (5e-12 mm at order 20, 1e-10 at 30 for these amplitudes) and whose default-INTEGER `2**n` overflows
     at n = 31 (sign flip; division by zero from 32 on) -- the kernels' three-term recurrences do neither, so
-    beyond ~order 25 the two part ways and it is the reference that is wrong (tools/dev/ll_debug.py)."""
+    beyond ~order 25 the two part ways and it is the reference that is wrong (tests/soak/ll_debug.py)."""
     rng = np.random.default_rng(1000 * kt + ka)
     base = {name: (fn, cols, args) for name, fn, cols, args in cases.cases(num=300, seed=99)}
     nc = (ka + 1) * (kt + 1)
