@@ -73,6 +73,29 @@ for it in range(iters):
     ct = cases._randrays(rng, n); ct["x"] = rng.uniform(-10, 10, n); ct["y"] = rng.uniform(-10, 10, n); ct["z"] = rng.uniform(5, 15, n)
     ct["l"] *= .1; ct["m"] *= .1; ct["n"] = -np.sqrt(1 - ct["l"] ** 2 - ct["m"] ** 2)
     check("torus", "surfacesf.torus", ct, (float(rng.uniform(100., 400.)), float(rng.uniform(800., 3000.))))
+    # cylindrical conic, conic + even polynomial (OPD too), 2-D Legendre phase surface, paraxial lenses, OPD variants
+    cy = cases._randrays(rng, n); cy["x"] = rng.uniform(-20, 20, n); cy["y"] = rng.uniform(5, 10, n)
+    cy["l"] = rng.uniform(-.05, .05, n); cy["n"] = rng.uniform(-.05, .05, n); cy["m"] = -np.sqrt(1 - cy["l"] ** 2 - cy["n"] ** 2)
+    check("cylconic", "surfacesf.cylconic", cy, (float(rng.choice([-1, 1]) / rng.uniform(300., 1500.)), float(rng.choice([-1., .5, 0., rng.uniform(-2, 1)]))))
+    npc = int(rng.integers(1, 17))
+    pp = rng.normal(0, 1., npc) * 10. ** (-6. - 4. * np.arange(npc))
+    cp = cases._randrays(rng, n); cp["x"] = rng.uniform(-30, 30, n); cp["y"] = rng.uniform(-30, 30, n); cp["z"] = rng.uniform(20, 40, n)
+    cp["l"] *= .1; cp["m"] *= .1; cp["n"] = -np.sqrt(1 - cp["l"] ** 2 - cp["m"] ** 2)
+    Rp, Kp = float(rng.choice([-1, 1]) * rng.uniform(400., 2000.)), float(rng.uniform(-1.5, .5))
+    check("conicplus", "surfacesf.conicplus", cp, (Rp, Kp, pp))
+    check("conicplusopd", "surfacesf.conicplusopd", {k: v.copy() for k, v in cp.items()}, (Rp, Kp, pp, 1.5))
+    nc = int(rng.integers(1, 40)); om = int(rng.integers(0, 13))
+    cl = cases._randrays(rng, n); cl["x"] = rng.uniform(-12, 12, n); cl["y"] = rng.uniform(-8, 8, n)
+    cl["l"] *= .05; cl["m"] *= .05; cl["n"] = np.sqrt(1 - cl["l"] ** 2 - cl["m"] ** 2) * rng.choice([-1., 1.], n)
+    check("legsurf", "surfacesf.legsurf", cl, (10., 10., float(rng.choice([1e-3, 1., 2.4e-6])), rng.normal(0, .1, nc),
+                                                   rng.integers(0, om + 1, nc).astype(np.int32), rng.integers(0, om + 1, nc).astype(np.int32)))
+    check("paraxial", "surfacesf.paraxial", cases._randrays(rng, n), (float(rng.choice([-1, 1]) * rng.uniform(20., 2000.)),))
+    check("paraxialy", "surfacesf.paraxialy", cases._randrays(rng, n), (float(rng.choice([-1, 1]) * rng.uniform(20., 2000.)),))
+    check("flatopd", "surfacesf.flatopd", cases._randrays(rng, n), (float(rng.uniform(1., 2.)),))
+    for fn_ in ("tracesphereopd", "tracecylopd"):
+        cs = cases._randrays(rng, n); cs["x"] = rng.uniform(-40, 40, n); cs["y"] = rng.uniform(-40, 40, n); cs["z"] = rng.uniform(150, 250, n)
+        cs["l"] *= .2; cs["m"] *= .2; cs["n"] = -np.sqrt(1 - cs["l"] ** 2 - cs["m"] ** 2)
+        check(fn_, "surfacesf." + fn_, cs, (float(rng.uniform(60., 400.)), float(rng.uniform(1., 2.))))
     # W-S designs: alpha, z0, psi (+ thickness): RMS position error
     alpha = .25 * math.atan(r0 / z0)
     cw = annulus(r0, z0, 1., L, 1e-4)
