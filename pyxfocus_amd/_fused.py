@@ -26,7 +26,7 @@ flat / transform / itransform / reflect / wolterprimary / woltersecondary / radg
 without ``ind=`` run through a kernel that reaches the HBM roof by giving up bit identity (same
 Newton steps on the exact quadratic along the ray, reciprocal-based divides, FMA) -- agreement
 with the reference < 1e-10 mm RMS on the BASELINE configs (z0 = 8.4 m), i.e. inside the reference's own rounding
-jitter -- which grows with the square of the focal length: 1-3e-10 mm at z0 = 15-20 m.
+jitter -- which grows with the square of the focal length: 1-6e-10 mm at z0 = 15-20 m.
 Programs holding anything else run through the exact kernel as usual.  The default stays bit-identical, and the
 straight-line form of the bit-exact two-bounce program runs within ~5 % of this mode's speed.
 """

@@ -30,6 +30,18 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
         surf.woltersecondary(rays, r0, z0, psi); tran.reflect(rays)
         surf.flat(rays)
     assert rec.fast_launches == 1
+    # the BIT-EXACT program (straight-line kernel) on the same design: every bit
+    from util import bits_equal
+    rb = [torch.from_numpy(c[k].copy()).cuda() for k in ALLCOLS]
+    with pxf.fused() as rec2:
+        tran.transform(rb, 0, 0, -(z0 + 2 * L), 0, 0, 0)
+        surf.wolterprimary(rb, r0, z0, psi); tran.reflect(rb)
+        surf.woltersecondary(rb, r0, z0, psi); tran.reflect(rb)
+        surf.flat(rb)
+    assert rec2.launches == 1
+    for k, v in zip(ALLCOLS, rb):
+        if not bits_equal(v.cpu().numpy(), want[k]).all():
+            print("EXACT PROGRAM MISMATCH r0 %.17g z0 %.17g psi %g col %s: %d rays" % (r0, z0, psi, k, int((~bits_equal(v.cpu().numpy(), want[k])).sum())))
     got = {k: v.cpu().numpy() for k, v in zip(ALLCOLS, rays)}
     ok = np.isfinite(want["x"]) & np.isfinite(got["x"])
     d2 = sum((got[k][ok] - want[k][ok]) ** 2 for k in "xyz")
