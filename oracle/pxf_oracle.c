@@ -1441,8 +1441,9 @@ int32_t orc_reconstruct(double *xang, double *yang, int32_t xdim, int32_t ydim, 
 void orc_cos_atan2(const double *r, const double *z, double *beta, double *cosbeta, double *tanhalf, int64_t num)
 {
     for (int64_t i = 0; i < num; i++) {
+        double sb;
         beta[i] = atan2(r[i], z[i]);
-        cosbeta[i] = cos(beta[i]);
+        sincos(beta[i], &sb, &cosbeta[i]);   /* the reference binary: one sincos for sin(beta), cos(beta) */
         tanhalf[i] = tan(beta[i] / 2);
     }
 }

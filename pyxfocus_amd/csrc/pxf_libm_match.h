@@ -4,13 +4,14 @@
 // steps of 2.6e-9 mm, so the converged point equals the reference's only if the whole Newton path does
 // (DESIGN.md section 4).
 //
-// The reference calls `cos(beta)`, `beta = atan2(sqrt(x**2+y**2), z)`, through glibc (2.35 in this image, FMA
-// build selected at load time on every AVX2 host).  glibc's cosine for 2^-27 < |x| < 0.855 is a PUBLISHED
-// algorithm (IBM Accurate Mathematical Library, "do_cos": x = xi + t with xi = k/128 from adding 1.5*2^45,
-// sin/cos(xi) from a head+tail table, short Taylor polynomials in t, one compensated combination) and is NOT
-// correctly rounded: ~5e-4 of its results are the other neighbour.  It is restated here operation by
-// operation -- including which products the library's FMA build fuses -- with the table regenerated from
-// 113-bit arithmetic (pxf_trig_tables.h); tests/test_host.py holds it to libm's `cos` bit for bit over the
+// The reference's `sin(beta)`, `cos(beta)` with `beta = atan2(sqrt(x**2+y**2), z)` compile (flang and gcc alike) to ONE
+// call of glibc's `sincos`, `tan(beta/2)` to `tan`.  Both are PUBLISHED algorithms (IBM Accurate Mathematical Library):
+// the cosine splits x = k/128 + t by adding 1.5*2^45, takes sin/cos(k/128) from a head+tail table, two short Taylor
+// polynomials in t and one compensated combination; it is NOT correctly rounded (~5e-4 of its results are the other
+// neighbour), and the `sincos` build (plain multiplies and adds) differs again from the `cos()` build (FMA) in 2.5e-5
+// of the arguments of the W-S range -- round 2 first restated `cos()` and sat at 2.1e-11 mm RMS with 1 ray in 1e4
+// off, then the `sincos` build: 1.0e-12, none off.  They are restated here operation by operation with the table
+// regenerated from 113-bit arithmetic (pxf_trig_tables.h); tests/test_host.py holds them to libm bit for bit over the
 // whole range on the machine the tests run on.  `beta` itself is formed as the correctly rounded arctangent
 // (double-double reduction against tan(k/128)), which is what glibc's atan2 returns in 99.8 % of the cases.
 //
@@ -25,27 +26,6 @@
 #include "pxf_trig_tables.h"
 
 namespace pxf {
-
-// glibc s_sin.c: do_cos(x, 0) for 2^-27 < |x| < 0.85546875 (the caller guarantees the range).
-__host__ __device__ __forceinline__ double libm_cos_small(double x, const double *__restrict__ sincos_tab)
-{
-    const double big = 0x1.8p45;
-    const double sn3 = -1.66666666666664880952546298448555E-01, sn5 = 8.33333214285722277379541354343671E-03;
-    const double cs2 = 4.99999999999999999999950396842453E-01, cs4 = -4.16666666666664434524222570944589E-02,
-                 cs6 = 1.38888874007937613028114285595617E-03;
-    const double ax = fabs(x);
-    const double u = big + ax;          // rounds |x| to a multiple of 1/128; the multiple sits in the low word
-    uint64_t ub;
-    memcpy(&ub, &u, 8);
-    const int k = (int)(uint32_t)(ub & 0xffffffffu) * 4;
-    const double t = ax - (u - big);    // exact
-    const double sn = sincos_tab[k], ssn = sincos_tab[k + 1], cs = sincos_tab[k + 2], ccs = sincos_tab[k + 3];
-    const double tt = t * t;
-    const double s = fma(t * tt, fma(tt, sn5, sn3), t);
-    const double c = tt * fma(tt, fma(tt, cs6, cs4), cs2);
-    const double cor = fma(-sn, s, fma(-cs, c, fma(-s, ssn, ccs)));
-    return cs + cor;
-}
 
 // glibc s_tan.c, the polynomial branch 1.259e-8 < |x| <= 0.0608 (FMA build): x + x^3 (d3 + x^2 (d5 + ...)).
 // The W-S secondary's kterm = tan(beta/2)**2 / tan(betas/2)**2 - 1 vanishes at the edge beta = betas of the
@@ -62,6 +42,8 @@ __host__ __device__ __forceinline__ double libm_tan_small(double x)
     t2 = fma(x2, t2, d3);
     return fma(t2, x * x2, x);
 }
+
+__host__ __device__ __forceinline__ double libm_sc_cos(double x, double dx, const double *__restrict__ tab);
 
 // beta = atan2(r, z) and cos(beta) as the reference's libm returns them, for r >= 0, z > 0 with
 // r/z < tan(0.855) (beta inside do_cos' range).  Returns false outside that range (caller falls back).
@@ -88,7 +70,9 @@ __host__ __device__ __forceinline__ bool libm_cos_atan2(double r, double z, cons
     const double e1 = (xi - (s1 - b2)) + (wh - b2);
     beta = s1 + (e1 + lo);
     if (!(beta < 0.85546875)) return false;
-    cb = libm_cos_small(beta, sincos_tab);
+    // the reference binary takes sin(beta), cos(beta) from ONE `sincos` call (woltsurf.f95:516-520 compiled): the
+    // non-FMA build of the cosine, which differs from `cos()` in 2.5e-5 of the arguments of this range
+    cb = libm_sc_cos(beta, 0., sincos_tab);
     return true;
 }
 

@@ -530,14 +530,14 @@ def test_nontemporal_instantiations_in_child_process():
 
 def test_tolerance_mirrors_rms_position_parity(port):
     """Parity of the tolerance-parity mirrors the way the north-star states it: RMS ray-position error
-    vs the oracle < 1e-10 mm -- observed 0 (woltersine, the Legendre-Legendre family), 1-2e-12 (W-S primaries,
-    `wssecondaryback`), 2.1e-11 (`wssecondary`: 1 ray in 1e4 takes the neighbouring quantum).  The W-S
-    SECONDARIES are the delicate ones, and the cause is the reference's own conditioning: `a` in
-    woltsurf.f95:518-519 contains (1 - cos beta) with cos beta ~ 1 - 3e-4, so F is QUANTISED in steps of
-    2.6e-9 mm (one ulp of cos beta) and the converged point equals the reference's only if the whole Newton path
-    does, bit for bit -- which is why the kernels restate the C library's cos / tan / sincos and form the
-    correctly rounded atan2 (pxf_libm_match.h; round 1 sat at 2e-9 RMS, round 2 first at 1.2e-10 with 0.5 % of
-    the rays one quantum off).  Recorded per surface: RMS, median, share of rays further than 1e-10 mm."""
+    vs the oracle < 1e-10 mm -- observed 0 (woltersine, the Legendre-Legendre family) and 1-4e-12 (all four W-S
+    surfaces, no ray further than 4e-11).  The W-S SECONDARIES are the delicate ones, and the cause is the
+    reference's own conditioning: `a` in woltsurf.f95:518-519 contains (1 - cos beta) with cos beta ~ 1 - 3e-4, so F
+    is QUANTISED in steps of 2.6e-9 mm (one ulp of cos beta) and the converged point equals the reference's only
+    if the whole Newton path does, bit for bit -- which is why the kernels restate the C library's sincos / tan and
+    form the correctly rounded atan2 (pxf_libm_match.h; round 1 sat at 2e-9 RMS, round 2 at 1.2e-10 with the
+    correctly rounded cosine, 2.1e-11 with libm's `cos()`, 1.0e-12 with the `sincos` build the reference binary
+    really calls).  Recorded per surface: RMS, median, share of rays further than 1e-10 mm."""
     stats = {}
     for name, fn, cols, args in cases.cases(num=50000, seed=4321):
         if not any(t in fn for t in ("ws", "ll", "woltersine")):
@@ -555,7 +555,7 @@ def test_tolerance_mirrors_rms_position_parity(port):
     assert len(stats) == 8
     for name, (rms, med, frac, mx) in stats.items():
         if name.startswith("wssecondary"):
-            assert rms < 5e-11 and med < 1e-12 and frac < 1e-3 and mx < 2e-8, (name, rms, med, frac, mx)
+            assert rms < 2e-11 and med < 1e-12 and frac < 2e-4 and mx < 2e-8, (name, rms, med, frac, mx)
         else:
             assert rms < 1e-10 and frac == 0., (name, rms, med, frac, mx)
 

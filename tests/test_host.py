@@ -344,12 +344,12 @@ def test_zernike_monomial_expansion_matches_reference_zernset(port, nmax):
 def test_ws_secondary_cos_beta_matches_libm_bitwise():
     """The Wolter-Schwarzschild secondary's `(1 - cos(beta))`, beta = atan2(r, z), turns one ulp of the C
     library's cosine into 2.6e-9 mm, and that cosine is not correctly rounded -- so the
-    kernels restate it, and the library's tangent polynomial for `tan(beta/2)` (pxf_libm_match.h).  Host copy
-    of the very same routines (pxf_host_cos_atan2) against the C library on THIS machine (oracle.orc_cos_atan2 =
-    libm's atan2, cos, tan -- the calls woltsurf.f95:510-520 makes): cosine and tangent bit for bit for every
-    beta libm and the restatement agree on (the restated arctangent is the correctly rounded one, libm's is
-    that in all but ~2e-3 of the cases), and the composition cos(atan2(r, z)) in all but 5e-4 of the cases over
-    the whole range, 1e-4 in the W-S range."""
+    kernels restate it (the `sincos` build the reference binary calls), and the library's tangent polynomial for
+    `tan(beta/2)` (pxf_libm_match.h).  Host copy of the very same routines (pxf_host_cos_atan2) against the C library
+    on THIS machine (oracle.orc_cos_atan2 = libm's atan2, sincos, tan -- the calls woltsurf.f95:510-520 compiles to):
+    cosine and tangent bit for bit for every beta libm and the restatement agree on (the restated arctangent is the
+    correctly rounded one, libm's is that in all but ~2e-3 of the cases), and the composition cos(atan2(r, z)) in all
+    but 5e-4 of the cases over the whole range, 1e-4 in the W-S range."""
     import ctypes as C
     from oracle import api
     from pyxfocus_amd import _lib
