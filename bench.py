@@ -307,7 +307,9 @@ def bench_config3(n, steps, dev, pxf, sources, tran, surf, con):
         with pxf.fused(fast=True):
             wl.config3_chain(r, tran, surf)
     parf = parity_vs_checker(lambda r, t, s: wl.config3_chain(r, t, s), fast_chain, cols, dev,
-                             "opt-in tolerance mode: < 1e-10 mm RMS (the reference's own 1-ulp jitter is ~5e-11)")
+                             "opt-in tolerance mode, does NOT meet the metric: headline = rms_pos_err_incl_flips_mm "
+                             "(all rays; ~1e-7 mm from the few fp32-flat flips); rms_pos_err_mm excludes those rays "
+                             "(< 1e-10 mm for z0 <= 12 m; the reference's own 1-ulp jitter is ~5e-11)")
     return {"workload": "config3: %g rays subannulus -> config-2 chain -> transform -> flat -> reflect -> radgrat "
                         "-> itransform -> flat (one radial grating, 160 nm at the hub distance, order 1, 2.4 nm)" % n,
             "rays": n, "steps": steps, "launches_per_step": 12, "algorithmic_bytes_per_ray": wl.BYTES["config3"],
@@ -499,6 +501,7 @@ def bench_config5(n, steps, dev, rank, world, dist, pxf, anal, tran, surf, grata
     if dist:
         from pyxfocus_amd import dist as pdist
         torch.cuda.synchronize(); dist.barrier()
+        torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
         gx, gy, gw = pdist.all_gather_focal([fx, fy, w])
         torch.cuda.synchronize(); dist.barrier()
@@ -588,8 +591,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1 or os.environ.get("PXF_BENCH_FORCE_DIST"):     # (the env knob rehearses the RCCL path on 1 GPU)
+    if world > 1 or os.environ.get("PXF_BENCH_FORCE_DIST"):     # (the env knob runs the RCCL path on 1 GPU)
         import torch.distributed as dist
+        if "WORLD_SIZE" not in os.environ:                       # forced, no launcher: a one-rank group of our own
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]), RANK="0",
+                              WORLD_SIZE="1", LOCAL_RANK=str(local))
+            s_.close()
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -714,8 +723,11 @@ def main():
         return {"value": N * n_gpus * K / felapsed, "unit": "rays/s", "ms_per_step": felapsed / K * 1e3,
                 "launches_per_step": 1, "algorithmic_bytes_per_ray": 120, "avg_launch_ms": fms,
                 "GBps": 120.0 * N / (fms * 1e-3) / 1e9, "frac_of_hbm_peak": 120.0 * N / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": ("pyxfocus_amd.fused(fast=True): OPT-IN tolerance mode (pxf_program_run_fast), < 1e-10 mm RMS vs "
-                         "the reference; reported beside, never instead of, the bit-exact numbers") if fast else
+                "note": ("pyxfocus_amd.fused(fast=True): OPT-IN tolerance mode (pxf_program_run_fast); NOT bit-identical "
+                         "and not a 1e-10 mm RMS path over all rays: ~2.5 rays per million flip the fp32 rounding of a "
+                         "flat and land 2.6e-5 mm aside (all-ray RMS ~1e-7 mm when any is present; see cpu_baseline."
+                         "parity_vs_gpu.fused_fast_rms_pos_err_incl_flips_mm), 5.5e-11 mm RMS with those set aside, z0 <= "
+                         "12 m; reported beside, never instead of, the bit-exact numbers") if fast else
                 "pyxfocus_amd.fused(): same calls recorded and run as one ray-program kernel, bit-identical"}
 
     fused = fused_fast = None
@@ -764,6 +776,8 @@ def main():
             def work():
                 try:
                     torch.cuda.set_device(local)
+                    if os.environ.get("PXF_BENCH_INJECT_C5_FAIL") == str(rank):      # (test hook: tests/test_gpu_dist.py)
+                        raise RuntimeError("injected config-5 failure on rank %d" % rank)
                     box["r"] = bench_config5(int(args.config_rays), args.config_steps, dev, rank, world, dist, pxf, anal,
                                              tran, surf)
                 except Exception as e:
@@ -779,6 +793,21 @@ def main():
             except Exception as e:
                 c5 = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
+
+    # Did config 5 fail or hang on ANY rank?  The flag travels through the rendezvous store (TCP), not through a
+    # collective: a rank stuck in one cannot answer, and its silence is the answer.
+    bad_ranks = []
+    if dist and c5 is not None:
+        try:
+            from datetime import timedelta
+            store = dist.distributed_c10d._get_default_store()
+            store.set("pxf_bench_c5_%d" % rank, "bad" if c5_trouble else "ok")
+            store.wait(["pxf_bench_c5_%d" % r for r in range(world)], timedelta(seconds=120))
+            bad_ranks = [r for r in range(world) if store.get("pxf_bench_c5_%d" % r) != b"ok"]
+        except Exception as e:
+            bad_ranks = ["unknown: " + repr(e)[:120]]
+        if bad_ranks and "error" not in c5:
+            c5["error"] = "config 5 failed or timed out on rank(s) %s" % bad_ranks
 
     out = None
     if rank == 0:
@@ -835,9 +864,15 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist:
-        if c5_trouble:               # ranks may be out of step: no further collective, leave now (line already printed)
+        if bad_ranks:
+            # Ranks may be out of step: no further collective.  Every rank leaves with a NON-ZERO status (rank 0's
+            # line, carrying the error, is already printed): a launcher keying on the exit code must not record a
+            # clean scaling point.
+            sys.stderr.write("bench.py: rank %d: config 5 failed or timed out on rank(s) %s -- exit status 3\n"
+                             % (rank, bad_ranks))
             sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(3)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -46,6 +46,10 @@ typedef void *pxf_stream_t; /* hipStream_t */
 int pxf_abi_version(void);
 const char *pxf_strerror(int code);
 int pxf_last_hip_error(void); /* hipError_t of the last failing HIP call on this thread */
+/* PXF_OK if the calling thread's current HIP device is a gfx950 (the only code object the library carries),
+ * PXF_ENODEV otherwise (no device, or another architecture).  Every launch makes the same check and returns
+ * PXF_ENODEV itself; this entry lets a binding ask up front.  Cached per device ordinal. */
+int pxf_device_check(void);
 
 /* ---- surfacesf.f95 --------------------------------------------------------------------- */
 
@@ -339,6 +343,18 @@ int pxf_moments(const double *x, const double *y, const double *l, const double 
 int pxf_central_moments(const double *x, const double *y, const double *w, int64_t num, double cx,
                         double cy, double *out_dev, void *workspace, pxf_stream_t stream);
 
+/* One step of surfaces.focus / focusX / focusY / focusI (surfaces.py:502-519) in ONE pass over the bundle:
+ *     transform(x..uz, tx,ty,tz, rx,ry,rz)   transformationsf.f95:134-163   (the wrapper's negated arguments)
+ *     flat(x..uz)  /  flatOPD(x..uz, opd, nr) if opd != NULL                  surfacesf.f95:4-53
+ *     moments_dev[PXF_NMOM] = the twelve sums above of the RESULT, weights w (NULL: unit), if moments_dev != NULL
+ * Per ray the same arithmetic as the three separate entries, in the same order: rays and sums come out with the same
+ * bits as pxf_transform -> pxf_flat[opd] -> pxf_moments.  104 B/ray (96 without the sums) instead of 80 + 96 + 48.
+ * `workspace` as pxf_moments (only used with moments_dev).  No mask: focus() has no `ind`. */
+int pxf_transform_flat_moments(double *opd, double *x, double *y, double *z, double *l, double *m, double *n,
+                               double *ux, double *uy, double *uz, const double *w, int64_t num, double tx, double ty,
+                               double tz, double rx, double ry, double rz, double nr, double *moments_dev,
+                               void *workspace, pxf_stream_t stream);
+
 /* analyses.rho (analyses.py:60-71): out[i] = sqrt((x-cx)^2 + (y-cy)^2) */
 int pxf_rho(const double *x, const double *y, double cx, double cy, double *out, int64_t num,
             pxf_stream_t stream);
@@ -588,12 +604,16 @@ int pxf_fan_finish(double *const *cols, int64_t num, double ang, double dpermm, 
  * fp64 divides instead of HBM.  The _fast entries run the same program to a TOLERANCE instead: the
  * Wolter-I Newton loops iterate the exact quadratic F(s) along the ray (same steps, same stopping
  * rule, same stale-gradient normal as woltsurf.f95:28-47,134-154), divides and square roots are
- * reciprocal / rsqrt refinements, FMA contraction is on.  Agreement with the reference: inside the
- * reference's own rounding jitter (its focal positions move by ~5e-11 mm RMS under a 1-ulp change of
- * an input) -- < 1e-10 mm RMS on the BASELINE configs, asserted in tests/.
+ * reciprocal / rsqrt refinements, FMA contraction is on.  Agreement with the reference (the figures
+ * are asserted in tests/test_gpu_fused.py): the all-ray RMS position error is ~1e-7 mm -- NOT under the 1e-10 mm
+ * bar -- because about 2.5 rays per million have the fp32-rounded propagation distance of a `flat`
+ * (surfacesf.f95:4-15) fall on the other side and land one fp32 quantum of their path (2.6e-5 mm at 8.4 m) aside;
+ * with those fp32-flat flips set aside it is 5.5e-11 (two-bounce) / 7.5e-11 mm (two-bounce + grating) RMS, the
+ * size of the reference's own rounding jitter under a 1-ulp change of an input -- for focal lengths z0 <= 12 m;
+ * the jitter grows as z0^2 (1-6e-10 mm at 15-20 m).
  * Supported operations: FLAT, TRANSFORM, ITRANSFORM, REFLECT, WOLTERPRIMARY, WOLTERSECONDARY,
- * RADGRAT, SPOCONE, unmasked; anything else returns PXF_ERANGE and nothing is launched (run the exact
- * entry instead).  Never selected implicitly. */
+ * RADGRAT, SPOCONE, INDANGLE (aux = the OUTPUT column), unmasked; anything else returns PXF_ERANGE and nothing is
+ * launched (run the exact entry instead).  Never selected implicitly. */
 int pxf_program_run_fast(const pxf_op_t *ops, int32_t nops, double *const *cols, int64_t num, pxf_stream_t stream);
 int pxf_program_run_segments_fast(const pxf_op_t *ops, int32_t nops, const double *seg_params_dev, int32_t nseg,
                                   int64_t rays_per_seg, double *const *cols, int64_t num, pxf_stream_t stream);

@@ -13,5 +13,5 @@ include/pxf.h (pyxfocus_amd/csrc/libpxf_hip.so).  There is no CPU fallback.
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401  (does not load the shared library until first use)
-from ._fused import compile_segments, flush, fused  # noqa: E402,F401
+from ._fused import FastModeWarning, compile_segments, flush, fused  # noqa: E402,F401
 from ._graph import capture  # noqa: E402,F401

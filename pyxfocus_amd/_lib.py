@@ -28,6 +28,7 @@ _SIGS = {
     "pxf_abi_version": [],
     "pxf_strerror": [C.c_int],
     "pxf_last_hip_error": [],
+    "pxf_device_check": [],
     "pxf_flat": [_P] * 9 + [_i64, _P, _P],
     "pxf_flatopd": [_P] * 10 + [_i64, _d, _P, _P],
     "pxf_conic": [_P] * 9 + [_i64, _d, _d, _P, _P],
@@ -80,6 +81,7 @@ _SIGS = {
     "pxf_reduce_workspace_bytes": [],
     "pxf_moments": [_P] * 6 + [_i64, _P, _P, _P],
     "pxf_central_moments": [_P] * 3 + [_i64, _d, _d, _P, _P, _P],
+    "pxf_transform_flat_moments": [_P] * 11 + [_i64] + [_d] * 7 + [_P, _P, _P],
     "pxf_rho": [_P, _P, _d, _d, _P, _i64, _P],
     "pxf_dist3": [_P, _P, _P, _d, _d, _d, _P, _i64, _P],
     "pxf_indangle": [_P] * 7 + [_i64, _i32, _P],

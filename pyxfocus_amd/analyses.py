@@ -418,9 +418,7 @@ def sellmeier(wave, B, C):
     return np.sqrt(1 + np.sum(num / den, axis=1))
 
 
-def analyticImagePlane(rays, weights=None, group=None):
-    """Best-focus shift by the analytic method of Ron Elsner's paper (analyses.py:118-133)."""
-    s = _moments(rays, weights, group=group)
+def _image_plane(s):
     W = s[0]
     bx = s[5] / W - (s[1] / W) * (s[3] / W)
     ax = s[7] / W - (s[3] / W) ** 2
@@ -429,39 +427,79 @@ def analyticImagePlane(rays, weights=None, group=None):
     return -(bx + by) / (ax + ay)
 
 
-def analyticYPlane(rays, weights=None, group=None):
-    """analyses.py:135-144"""
-    s = _moments(rays, weights, group=group)
+def _y_plane(s):
     W = s[0]
     by = s[6] / W - (s[2] / W) * (s[4] / W)
     ay = s[8] / W - (s[4] / W) ** 2
     return -by / ay
 
 
-def analyticXPlane(rays, weights=None, group=None):
-    """analyses.py:146-155"""
-    s = _moments(rays, weights, group=group)
+def _x_plane(s):
     W = s[0]
     bx = s[5] / W - (s[1] / W) * (s[3] / W)
     ax = s[7] / W - (s[3] / W) ** 2
     return -bx / ax
 
 
+def analyticImagePlane(rays, weights=None, group=None):
+    """Best-focus shift by the analytic method of Ron Elsner's paper (analyses.py:118-133)."""
+    return _image_plane(_moments(rays, weights, group=group))
+
+
+def analyticYPlane(rays, weights=None, group=None):
+    """analyses.py:135-144"""
+    return _y_plane(_moments(rays, weights, group=group))
+
+
+def analyticXPlane(rays, weights=None, group=None):
+    """analyses.py:146-155"""
+    return _x_plane(_moments(rays, weights, group=group))
+
+
+# the scalar algebra behind each best-focus function, for callers that already hold the twelve sums (surfaces.focus)
+analyticImagePlane._from_sums = _image_plane
+analyticYPlane._from_sums = _y_plane
+analyticXPlane._from_sums = _x_plane
+
+
+def _focus_step(rays, dz, weights, nr, want_sums, group=None):
+    """transform(rays,0,0,dz,0,0,0) -> flat(rays, nr=nr) -> the twelve sums of the result (want_sums), as ONE
+    launch (pxf_transform_flat_moments): rays and sums have the bits of the three separate calls."""
+    fused.flush()
+    num, dev = native._check_cols(tuple(rays), "focus")
+    w = _weights(weights, num, dev) if want_sums else None
+    out = torch.zeros(_lib.PXF_NMOM, dtype=torch.float64, device=dev) if want_sums else None
+    p = [c.data_ptr() for c in rays]
+    if nr is None:
+        p[0] = None
+    with torch.cuda.device(dev):
+        # (the wrapper negates its arguments: transformations.py:29; focus passes integer zeros, whose negation is +0)
+        rc = _lib.lib().pxf_transform_flat_moments(*p, None if w is None else w.data_ptr(), num, 0., 0., -float(dz),
+                                                   0., 0., 0., 0. if nr is None else float(nr),
+                                                   None if out is None else out.data_ptr(),
+                                                   _workspace(dev).data_ptr(), native._stream(dev))
+    _lib.check(rc, "pxf_transform_flat_moments")
+    return _allreduce(out, group).tolist() if want_sums else None
+
+
 def indAngle(rays, ind=None, normal=None, _graze=0, out=None):
     """Incidence angle of the rays with either the current or a specified surface normal
     (analyses.py:164-182).  Returns a device tensor (of the `ind`-selected rays if ind is given).
 
-    Inside a ``pyxfocus_amd.fused()`` block (or a ``compile_segments`` function) a plain call -- no `ind`, no
-    `normal` -- is RECORDED as a program operation: the angles of the rays as they stand at that point
-    of the trace are written by the fused kernel itself, and the returned tensor is valid once the block has
-    run.  ``out=`` (an addition): the column to fill; in a segmented program pass the segment's slice of
-    one bundle-long column."""
+    ``out=`` (an addition): the column to fill.  Inside a ``pyxfocus_amd.fused()`` block (or a
+    ``compile_segments`` function) a call WITH ``out=`` -- and no `ind`, no `normal` -- is RECORDED as a program
+    operation: the angles of the rays as they stand at that point of the trace are written by the fused kernel
+    itself, and `out` is valid once the block has run (in a segmented program pass the segment's slice of one
+    bundle-long column).  WITHOUT ``out=`` the call flushes the pending program and launches, so the tensor it
+    returns is valid at once -- the reference's ``refl = reflectivity(grazeAngle(rays))`` (sector.py:592-612)
+    inside a fused block reads real angles, never memory a later launch will fill."""
     l, m, n, ux, uy, uz = rays[4:10]
     num, dev = native._check_cols((l, m, n, ux, uy, uz), "indAngle")
+    deferred_ok = out is not None          # only a caller who named the column has agreed to wait for the block
     if out is None:
         out = torch.empty_like(l)
     rec = fused.active()
-    if rec is not None and ind is None and normal is None and num:
+    if rec is not None and deferred_ok and ind is None and normal is None and num:
         cols = (l, m, n, ux, uy, uz, out)
         if rec.try_add("pxf_indangle", cols, (float(_graze),), None):
             return out

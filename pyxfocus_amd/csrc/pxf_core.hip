@@ -1,5 +1,6 @@
 // pxf_core.hip -- ABI version, error strings, per-thread HIP error slot, device query.
 #include <stdlib.h>
+#include <string.h>
 
 #include "pxf_kernel.h"
 
@@ -7,21 +8,41 @@ namespace pxf {
 
 thread_local int g_last_hip_error = 0;
 
-int device_cus()
+// Per-device facts, cached per device ORDINAL (a process may drive several GPUs; a CU count read on one must not
+// size a reduction launched on another): CU count, and whether the device can run this library's gfx950 code object.
+namespace {
+constexpr int kMaxDevices = 64;
+struct DevInfo {
+    int state = 0;  // 0 unknown, 1 usable gfx950, -1 not usable
+    int cus = 256;
+};
+DevInfo g_dev[kMaxDevices];
+
+const DevInfo &dev_info()
 {
-    // cached per process; a ray bundle lives on one device and MI355X nodes are homogeneous
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    static const DevInfo none{-1, 256};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return none;
+    DevInfo &d = g_dev[dev];
+    if (d.state == 0) {  // (a benign race: every thread would write the same values)
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        else
-            cus = 256;  // MI355X
+        DevInfo t;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) t.cus = prop.multiProcessorCount;
+            t.state = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : -1;
+        } else {
+            t.state = -1;
+        }
+        d.cus = t.cus;
+        d.state = t.state;
     }
-    return cus;
+    return d;
 }
+}  // namespace
+
+int device_cus() { return dev_info().cus; }
+
+bool device_usable() { return dev_info().state == 1; }
 
 int blocks_per_cu_cap()
 {
@@ -62,6 +83,8 @@ extern "C" {
 int pxf_abi_version(void) { return PXF_ABI_VERSION; }
 
 int pxf_last_hip_error(void) { return pxf::g_last_hip_error; }
+
+int pxf_device_check(void) { return pxf::device_usable() ? PXF_OK : PXF_ENODEV; }
 
 const char *pxf_strerror(int code)
 {

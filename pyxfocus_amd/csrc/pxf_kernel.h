@@ -203,10 +203,23 @@ int device_cus();
 int blocks_per_cu_cap();
 bool use_nt(int64_t num);  // bundle (80 B/ray) larger than the Infinity Cache -> non-temporal accesses  // 0 = no cap: one workgroup per 256 ray-vectors (env PXF_BPC overrides)
 
+bool device_usable();  // the current device is a gfx950 (cached per device ordinal)
+
+// A failed HIP call -> the C ABI's code.  "This device cannot run the library's gfx950 code object" (no device, an
+// invalid one, no binary for the GPU, kernel symbol not found on it) is PXF_ENODEV; everything else PXF_EHIP.
 inline int hip_fail(hipError_t e)
 {
     g_last_hip_error = (int)e;
-    return PXF_EHIP;
+    switch (e) {
+        case hipErrorNoDevice:
+        case hipErrorInvalidDevice:
+        case hipErrorNoBinaryForGpu:
+        case hipErrorInvalidDeviceFunction:
+        case hipErrorSharedObjectInitFailed:
+            return PXF_ENODEV;
+        default:
+            return device_usable() ? PXF_EHIP : PXF_ENODEV;
+    }
 }
 
 inline int grid_for(int64_t nvec)
@@ -243,6 +256,7 @@ int launch_rays(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t st
 {
     if (num < 0) return PXF_EINVAL;
     if (num == 0) return PXF_OK;  // an empty bundle is a no-op (its columns may be NULL)
+    if (!device_usable()) return PXF_ENODEV;
     bool aligned = true;
     for (int col = 0; col < NCOL; col++) {
         if ((Op::RD | Op::WR) & B(col)) {

@@ -31,7 +31,7 @@ def shard_range(total, rank=None, world=None):
 GATHER_SCRATCH_BYTES = 1 << 30      # bound on the staging memory of an uneven gather (send + world x recv)
 
 
-def all_gather_focal(cols, group=None, scratch_bytes=None):
+def all_gather_focal(cols, group=None, scratch_bytes=None, staged=None):
     """cols: list of equal-length 1-D tensors (this rank's surviving rays).  Returns a list of the
     same columns concatenated over ranks in rank order (i.e. global ray order).
 
@@ -42,7 +42,8 @@ def all_gather_focal(cols, group=None, scratch_bytes=None):
     its final tensor, no padding, no copy.  Uneven counts: every output column is allocated at its
     final size and filled by per-rank offsets through a fixed staging buffer of `scratch_bytes`
     ((world+1) equal chunks: one send slot, world receive slots); a rank whose slice fills the
-    chunk sends from its column directly."""
+    chunk sends from its column directly.  `staged=True` takes the staged path for equal shards too (the
+    bounded-memory route regardless of the count table; also how a one-rank run exercises it)."""
     world = dist.get_world_size(group)
     n = int(cols[0].shape[0])
     dev, dt = cols[0].device, cols[0].dtype
@@ -57,7 +58,7 @@ def all_gather_focal(cols, group=None, scratch_bytes=None):
     out = [torch.empty(total, dtype=dt, device=dev) for _ in cols]
     if total == 0:
         return out
-    if min(counts) == maxlen:                                     # equal shards: straight into place
+    if min(counts) == maxlen and not staged:                      # equal shards: straight into place
         for o, c in zip(out, cols):
             dist.all_gather_into_tensor(o, c.contiguous(), group=group)
         return out

