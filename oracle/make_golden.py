@@ -340,12 +340,47 @@ def gold_retrace(tran, src, anal, surf):
     print("retrace: centroid+rms perfect %s, tilted %s" % (blob["perfect/scalars"], blob["tilted/scalars"]))
 
 
+def write_provenance():
+    """Where the fixtures' numbers were made: the reference's host scalars (sin/cos of frame angles, Van Speybroeck
+    constants) and the W-S libm calls come from THIS machine's C library -- glibc selects sin / cos / sincos / tan per
+    CPU through ifunc, and the bit-identical parity claims are tied to that selection."""
+    import json
+    import platform
+    cpu = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    flags = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("flags"):
+                fl = ln.split(":", 1)[1].split()
+                flags = " ".join(f for f in ("fma", "avx2", "avx512f") if f in fl)
+                break
+    except OSError:
+        pass
+    json.dump({"libc": " ".join(platform.libc_ver()), "machine": platform.machine(), "cpu": cpu, "cpu_isa": flags,
+               "numpy": np.__version__, "python": platform.python_version(),
+               "compiler": "AMD flang (ROCm 7.2.0) -O2 for oracle/_ref; gcc -O2 -ffp-contract=off for oracle/pxf_oracle.c",
+               "note": "fixtures are data produced by the reference's own Fortran/Python on this machine; the GPU suite "
+                       "checks the box's libm against the restated routines first "
+                       "(tests/test_gpu_parity.py::test_box_libm_is_the_one_the_kernels_restate)"},
+              open(os.path.join(OUT, "PROVENANCE.json"), "w"), indent=1)
+
+
 def main():
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5, alignment, ws_heights, retrace")
+    ap.add_argument("--only", default="", help="comma list: legacy (the seven round-1 files), analyses, config5, alignment, ws_heights, retrace, provenance")
     only = [t for t in ap.parse_args().only.split(",") if t]
     os.makedirs(OUT, exist_ok=True)
+    write_provenance()
+    if only == ["provenance"]:
+        return
     ref = api.load_ref()
     tran, src = shim_reference_python(ref)
     if not only or set(only) & {"analyses", "config5", "alignment", "ws_heights", "retrace"}:

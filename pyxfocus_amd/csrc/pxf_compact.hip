@@ -33,7 +33,7 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long ballot)
 }
 
 // default predicate, transformations.py:221-223.  Two rays per thread, one 2-byte store.
-__global__ __launch_bounds__(kBlock) void vignette_mask_kernel(const double *__restrict__ l,
+__global__ __launch_bounds__(kBlock, 2) void vignette_mask_kernel(const double *__restrict__ l,
                                                                const double *__restrict__ m,
                                                                const double *__restrict__ n,
                                                                int64_t num, uint8_t *__restrict__ mask,
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void vignette_mask_kernel(const double *__r
 }
 
 // step 2a: per-tile counts
-__global__ __launch_bounds__(kBlock) void tile_count_kernel(const uint8_t *__restrict__ mask, int64_t num,
+__global__ __launch_bounds__(kBlock, 2) void tile_count_kernel(const uint8_t *__restrict__ mask, int64_t num,
                                                             int64_t *__restrict__ counts)
 {
     __shared__ unsigned s_w[kWavesPerBlock];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int64_t *__restrict__ o
 }
 
 // step 3: scatter all columns
-__global__ __launch_bounds__(kBlock) void compact_scatter_kernel(ColPtrs p, int ncols, int64_t num,
+__global__ __launch_bounds__(kBlock, 2) void compact_scatter_kernel(ColPtrs p, int ncols, int64_t num,
                                                                  const uint8_t *__restrict__ mask,
                                                                  const int64_t *__restrict__ offs)
 {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(ColPtrs p, int 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void gather_kernel(ColPtrs p, int ncols, const int64_t *__restrict__ idx,
+__global__ __launch_bounds__(kBlock, 2) void gather_kernel(ColPtrs p, int ncols, const int64_t *__restrict__ idx,
                                                         int64_t nidx, int64_t num, int *__restrict__ oob)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(ColPtrs p, int ncols, co
     }
 }
 
-__global__ __launch_bounds__(kBlock) void mask_from_index_kernel(const int64_t *__restrict__ idx, int64_t nidx,
+__global__ __launch_bounds__(kBlock, 2) void mask_from_index_kernel(const int64_t *__restrict__ idx, int64_t nidx,
                                                                  int64_t num, uint8_t *__restrict__ mask)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;

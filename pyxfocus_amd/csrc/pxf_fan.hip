@@ -65,11 +65,19 @@ __device__ __forceinline__ bool fan_in_range(const double *c, const FanGeom &g)
 }
 
 // A frame change whose translation is +0 and whose y and z angles are +0 (`transform(rays, 0, 0, 0, ang, 0, 0)`,
-// the fan's pitch) sends every vector through two rotations by zero: 1*x + 0*z ... -- the identity for every
-// component that is not -0, not infinite and not NaN (a -0 can come back +0, a NaN or infinity contaminates its
-// neighbours: those rays take the full arithmetic).  `v_cmp_class_f64` tests all three conditions in one
-// instruction; 15 class tests replace 39 multiplies and adds per round.
+// the fan's pitch) sends every vector through the rotation about x and then two rotations by zero: 1*x + 0*z ... --
+// the identity for every component that is not -0, not infinite and not NaN (a -0 can come back +0, a NaN or infinity
+// contaminates its neighbours: those rays take the full arithmetic).  `v_cmp_class_f64` tests all three conditions in
+// one instruction.  Only the values that ENTER the zero-angle rotations matter, i.e. the nine components AFTER the
+// rotation about x (which is always done in full): a special input y or z either makes its rotated images special
+// too (inf, NaN) or does not matter (-0 in, ordinary number out).  And the x-components (x, l, ux) pass the rotation
+// about x untouched, so inside a loop that only rotates they are tested once, not every round.
 __device__ __forceinline__ bool fan_special(double v) { return special_value(v); }   // pxf_ops_transforms.h
+// ... the same, or a zero of either sign (where "c*y" was written for "c*y - s*0", below)
+__device__ __forceinline__ bool fan_special_or_zero(double v)
+{
+    return __builtin_amdgcn_class(v, 0x001 | 0x002 | 0x004 | 0x020 | 0x040 | 0x200);
+}
 // +0 translation, (cos, sin) = (1, +0) about y and z -- compared as bit patterns (a -0 sine multiplies differently)
 __device__ __forceinline__ bool fan_x_only(const TransformOp<false> &rot)
 {
@@ -78,34 +86,32 @@ __device__ __forceinline__ bool fan_x_only(const TransformOp<false> &rot)
            __double_as_longlong(rot.cy) == one && __double_as_longlong(rot.sy) == 0 &&
            __double_as_longlong(rot.cz) == one && __double_as_longlong(rot.sz) == 0;
 }
-__device__ __forceinline__ void fan_rotate(const TransformOp<false> &rot, bool x_only, Ray (&r)[1])
+// A vector that ONLY rotates about x, round after round, needs no test per round at all.  With (c, s) = (cos, sin) of
+// the pitch both non-zero (fan_rot_window) and a pair (y, z) that holds no -0 / inf / NaN and whose larger magnitude
+// lies in [2^-400, 2^400] (fan_pair_window):
+//   * at least one of the products in  y' = c*y - s*z,  z' = s*y + c*z  is an ordinary non-zero number, so a result is
+//     either non-zero or the +0 of an exact cancellation -- never -0 (that takes two zero terms), never inf / NaN;
+//   * a rotation keeps max(|y|, |z|) to a few ulp, so the pair is inside the window again (1e5 rounds move it by 2^-35).
+// By induction every later round's rotated pair is plain, and plain values pass the two zero-angle rotations that
+// follow unchanged: the round is the rotation about x and nothing else.  The x-component never changes: tested once.
+__device__ __forceinline__ bool fan_pair_window(double y, double z)
 {
-    double *c = r[0].c;
-    if (x_only) {   // wave-uniform
-        double t[9];
-#pragma unroll
-        for (int j = 0; j < 9; j++) t[j] = c[X + j];
-        rotv<1>(t[0], t[1], t[2], rot.cx, rot.sx);
-        rotv<1>(t[3], t[4], t[5], rot.cx, rot.sx);
-        rotv<1>(t[6], t[7], t[8], rot.cx, rot.sx);
-        // every input component, and the rotated y, z that enter the zero-angle rotations next, must be plain
-        // (bitwise |: one lane mask per test, no short-circuit branches)
-        int bad = 0;
-#pragma unroll
-        for (int j = 0; j < 9; j++) bad |= (int)fan_special(c[X + j]);
-        bad |= (int)fan_special(t[1]) | (int)fan_special(t[2]) | (int)fan_special(t[4]) | (int)fan_special(t[5]) |
-               (int)fan_special(t[7]) | (int)fan_special(t[8]);
-        if (!bad) {
-#pragma unroll
-            for (int j = 0; j < 9; j++) c[X + j] = t[j];
-            return;
-        }
-    }
+    const double m = fmax(fabs(y), fabs(z));   // (NaN operands are caught by the class tests)
+    return !((int)special_value(y) | (int)special_value(z)) && m >= 0x1p-400 && m <= 0x1p400;
+}
+__device__ __forceinline__ bool fan_rot_window(const TransformOp<false> &rot)   // wave-uniform
+{
+    const double c = fabs(rot.cx), s = fabs(rot.sx);
+    return c >= 0x1p-100 && c <= 1. && s >= 0x1p-100 && s <= 1.;
+}
+// the whole frame change on the groups asked for (1 position, 2 direction, 4 normal), full arithmetic
+__device__ __forceinline__ void fan_rotate_full(TransformOp<false> rot, int groups, Ray (&r)[1])
+{
     const bool sel[1] = {true};
     unsigned wm[1];
+    rot.groups = groups;
     rot.apply<1>(r, sel, wm);
 }
-
 __device__ __forceinline__ void load9(const Cols &c, int64_t i, Ray &r)
 {
 #pragma unroll
@@ -117,25 +123,67 @@ __device__ __forceinline__ void store9(const Cols &c, int64_t i, const Ray &r)
     for (int col = X; col <= UZ; col++) c.p[col][i] = r.c[col];
 }
 
-__global__ __launch_bounds__(kBlock) void fan_search_kernel(Cols c, int64_t num, FanGeom g, int32_t *__restrict__ it_hit,
+// The search.  Per round the host loop does: frame change of all nine numbers, `flat` unless the ray is grazing,
+// range test.  What a ray that has just been through a `flat` carries is known: z = +0 and normal (0, 0, 1) -- so in
+// that state (every round but the grazing ones, which are rare) a round is
+//     y1 = c*y          for  c*y - s*(+0)      z1 = s*y       for  s*y + c*(+0)
+//     m1 = c*m - s*n    n1 = s*m + c*n                                         (l, x: untouched by a rotation about x)
+//     three class tests: x, y1, z1 (zeros count as special there: "- s*0" can turn a -0 into +0); the direction
+//                       only ever rotates, so ONE window test before the loop covers it for every round (above)
+//     the normal: NOT rotated -- the next flat overwrites it; only a round that turns out grazing needs the rotated
+//                 (0, 0, 1), and gets it from the full arithmetic then
+//     flat: the shared FlatOp::advance, position only
+// 10 multiplies / adds and 3 class tests where the generic round has 39 and 15.  Every other state (first round, after
+// a grazing round, any special value anywhere) takes the generic round, which is the full reference arithmetic.
+__global__ __launch_bounds__(kBlock, 2) void fan_search_kernel(Cols c, int64_t num, FanGeom g, int32_t *__restrict__ it_hit,
                                                             int32_t *__restrict__ imax, unsigned long long *__restrict__ nmiss)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const bool rot_window = fan_x_only(g.rot) && fan_rot_window(g.rot);   // wave-uniform
+    const double cx = g.rot.cx, sx = g.rot.sx;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
         Ray r[1];
         load9(c, i, r[0]);
-        const bool sel[1] = {true};
-        unsigned wm[1];
+        double *q = r[0].c;
         // round 0: the bundle as it arrives
-        if (fan_not_grazing(r[0].c[N], g)) FlatOp<false>{0.}.apply<1>(r, sel, wm);
-        bool hit = fan_in_range(r[0].c, g);
+        bool flat_prev = fan_not_grazing(q[N], g);   // "z = +0 and normal = (0,0,1) as the last flat left them"
+        if (flat_prev) {
+            FlatOp<false>::advance(q);
+            q[UX] = 0.;
+            q[UY] = 0.;
+            q[UZ] = 1.;
+        }
+        bool hit = fan_in_range(q, g);
         int it = 0;
-        const bool x_only = fan_x_only(g.rot);   // wave-uniform
+        // l never changes in the search and (m, n) only rotates: one test before the loop covers every round
+        const bool dir_plain = rot_window && !fan_special(q[L]) && fan_pair_window(q[M], q[N]);
         while (!hit && it < g.cap) {
             it++;
-            fan_rotate(g.rot, x_only, r);
-            if (fan_not_grazing(r[0].c[N], g)) FlatOp<false>{0.}.apply<1>(r, sel, wm);
-            hit = fan_in_range(r[0].c, g);
+            bool normal_pending = false;             // the normal still has to go through this round's frame change
+            bool done = false;
+            if (flat_prev && dir_plain) {
+                const double y1 = cx * q[Y], z1 = sx * q[Y];
+                const int bad = (int)fan_special(q[X]) | (int)fan_special_or_zero(y1) | (int)fan_special_or_zero(z1);
+                if (!bad) {
+                    q[Y] = y1;
+                    q[Z] = z1;
+                    rotv<1>(q[L], q[M], q[N], cx, sx);
+                    normal_pending = true;
+                    done = true;
+                }
+            }
+            if (!done) fan_rotate_full(g.rot, 7, r);
+            if (fan_not_grazing(q[N], g)) {
+                FlatOp<false>::advance(q);
+                q[UX] = 0.;
+                q[UY] = 0.;
+                q[UZ] = 1.;
+                flat_prev = true;
+            } else {
+                if (normal_pending) fan_rotate_full(g.rot, 4, r);   // (0,0,1) through this round's frame change
+                flat_prev = false;
+            }
+            hit = fan_in_range(q, g);
         }
         store9(c, i, r[0]);
         it_hit[i] = hit ? it : -1;
@@ -146,30 +194,36 @@ __global__ __launch_bounds__(kBlock) void fan_search_kernel(Cols c, int64_t num,
     }
 }
 
-__global__ __launch_bounds__(kBlock) void fan_finish_kernel(Cols c, int64_t num, TransformOp<false> rot, RadgratOp<false> grat,
-                                                            const int32_t *__restrict__ it_hit, int imax)
+// The finish.  After its one diffraction a ray only rotates, so the window argument above applies to all three of its
+// vectors: three x-components and three (y, z) pairs tested ONCE, then every round is the 18 multiplies and adds of the
+// rotation about x, in place.  A ray that fails the test takes the full frame change every round.
+__global__ __launch_bounds__(kBlock, 2) void fan_finish_kernel(Cols c, int64_t num, TransformOp<false> rot, RadgratOp<false> grat,
+                                                               const int32_t *__restrict__ it_hit, int imax)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const bool rot_window = fan_x_only(rot) && fan_rot_window(rot);   // wave-uniform
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
         const int it = it_hit[i];
         if (it < 0) continue;  // never met a grating (reported by the search): left as it stands
         Ray r[1];
         load9(c, i, r[0]);
+        double *q = r[0].c;
         const bool sel[1] = {true};
         unsigned wm[1];
-        bool pending = true;
-        const bool x_only = fan_x_only(rot);   // wave-uniform
-        for (int j = it + 1; j <= imax; j++) {
-            if (pending) {
-                ReflectOp{}.apply<1>(r, sel, wm);
-                grat.apply<1>(r, sel, wm);
-                pending = false;
+        // diffract once: at the start of round it+1, or after the loop for a ray that met its grating in the last round
+        // (sector.py:703-704) -- the same two operations either way
+        ReflectOp{}.apply<1>(r, sel, wm);
+        grat.apply<1>(r, sel, wm);
+        const bool plain = rot_window && !((int)fan_special(q[X]) | (int)fan_special(q[L]) | (int)fan_special(q[UX])) &&
+                           fan_pair_window(q[Y], q[Z]) && fan_pair_window(q[M], q[N]) && fan_pair_window(q[UY], q[UZ]);
+        if (plain) {
+            for (int j = it + 1; j <= imax; j++) {
+                rotv<1>(q[X], q[Y], q[Z], rot.cx, rot.sx);
+                rotv<1>(q[L], q[M], q[N], rot.cx, rot.sx);
+                rotv<1>(q[UX], q[UY], q[UZ], rot.cx, rot.sx);
             }
-            fan_rotate(rot, x_only, r);
-        }
-        if (pending) {  // met its grating in the last round: sector.py:703-704
-            ReflectOp{}.apply<1>(r, sel, wm);
-            grat.apply<1>(r, sel, wm);
+        } else {
+            for (int j = it + 1; j <= imax; j++) fan_rotate_full(rot, 7, r);
         }
         store9(c, i, r[0]);
     }

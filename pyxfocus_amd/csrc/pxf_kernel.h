@@ -138,9 +138,13 @@ __device__ __forceinline__ int64_t tile_of_block(int64_t b, int64_t nblocks, int
 
 // An Op may ask for a minimum occupancy (waves per SIMD) with `static constexpr int MIN_WAVES`: the
 // second __launch_bounds__ argument caps its VGPR budget accordingly (512 / MIN_WAVES per lane).
+// The default is 2, never 1: a 512-register budget lets the compiler park VGPRs in AGPRs, and its reload path for
+// those has been seen to drop half of a 64-bit copy (profiles/r02_zernike_miscompile.md).  Every kernel of the
+// library -- ray kernels through this default, the others through their own `__launch_bounds__(kBlock, 2)` -- is
+// therefore compiled for at most 256 registers; tests/test_kernel_resources.py audits the built code objects.
 template <class T, class = void>
 struct min_waves {
-    static constexpr int value = 1;
+    static constexpr int value = 2;
 };
 template <class T>
 struct min_waves<T, decltype((void)T::MIN_WAVES)> {

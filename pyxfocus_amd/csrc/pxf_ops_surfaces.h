@@ -21,17 +21,24 @@ struct FlatOp {
     static constexpr unsigned RD = POS | DIR | (WOPD ? B(OPD) : 0u);
     static constexpr unsigned WR = POS | NRM | (WOPD ? B(OPD) : 0u);
     double nr;
+    // the propagation itself (position only); returns the distance.  Shared with the fanned-grating kernels
+    // (pxf_fan.hip), which keep the normal implicit while a ray walks the fan.
+    static __device__ __forceinline__ double advance(double *c)
+    {
+        // `delta` is implicitly REAL*4 in the reference: round the distance to fp32
+        const float delta = (float)(-c[Z] / c[N]);
+        const double dd = (double)delta;
+        c[Z] = 0.;
+        c[X] = c[X] + dd * c[L];
+        c[Y] = c[Y] + dd * c[M];
+        return dd;
+    }
     template <int V>
     __device__ __forceinline__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const
     {
 #pragma unroll
         for (int k = 0; k < V; k++) {
-            // `delta` is implicitly REAL*4 in the reference: round the distance to fp32
-            const float delta = (float)(-r[k].c[Z] / r[k].c[N]);
-            const double dd = (double)delta;
-            r[k].c[Z] = 0.;
-            r[k].c[X] = r[k].c[X] + dd * r[k].c[L];
-            r[k].c[Y] = r[k].c[Y] + dd * r[k].c[M];
+            const double dd = advance(r[k].c);
             r[k].c[UX] = 0.;
             r[k].c[UY] = 0.;
             r[k].c[UZ] = 1.;

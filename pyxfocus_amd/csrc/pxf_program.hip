@@ -20,7 +20,7 @@ namespace pxf {
 // ANYMASK=false instantiations carry no per-op mask code (no saved copy of the ray -> fewer VGPRs)
 // HOT: every operation of the program is one of kHotOps (unmasked programs only): the 9-case interpreter step
 template <int V, bool NT, bool ANYMASK, bool HOT = false>
-__global__ __launch_bounds__(kBlock) void program_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
+__global__ __launch_bounds__(kBlock, 2) void program_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void exec_fixed(int flags, const double *__restrict__
 }
 
 template <int V, bool NT, int... CODES>
-__global__ __launch_bounds__(kBlock) void program_chain_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
+__global__ __launch_bounds__(kBlock, 2) void program_chain_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
@@ -190,7 +190,7 @@ struct SegInfo {
 
 // CODES...: a compile-time operation sequence (straight-line form, see above); empty = the interpreter
 template <bool NT, bool ANYMASK, bool HOT = false, int... CODES>
-__global__ __launch_bounds__(kBlock) void program_seg_kernel(Cols c, int64_t nvec, Program pg, SegInfo sg)
+__global__ __launch_bounds__(kBlock, 2) void program_seg_kernel(Cols c, int64_t nvec, Program pg, SegInfo sg)
 {
     constexpr int V = 2;
     __shared__ double s_par[kMaxSegPerBlock][kMaxOps][9];

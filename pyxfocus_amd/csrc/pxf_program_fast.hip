@@ -360,7 +360,7 @@ static bool fast_supported(const Program &pg)
 }
 
 template <int V, bool NT, int... CODES>
-__global__ __launch_bounds__(kBlock) void program_fast_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
+__global__ __launch_bounds__(kBlock, 2) void program_fast_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
@@ -407,7 +407,7 @@ struct FastSegInfo {
 };
 
 template <bool NT, int... CODES>
-__global__ __launch_bounds__(kBlock) void program_fast_seg_kernel(Cols c, int64_t nvec, Program pg, FastSegInfo sg)
+__global__ __launch_bounds__(kBlock, 2) void program_fast_seg_kernel(Cols c, int64_t nvec, Program pg, FastSegInfo sg)
 {
     constexpr int V = 2;
     __shared__ double s_par[kFastMaxSegPerBlock][kMaxOps][9];

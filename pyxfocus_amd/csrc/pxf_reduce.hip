@@ -61,7 +61,7 @@ __device__ __forceinline__ void mom_accum(double (&acc)[PXF_NMOM], double ww, do
 }
 
 template <int V, bool HASDIR, bool HASW>
-__global__ __launch_bounds__(kBlock) void moments_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(kBlock, 2) void moments_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                          const double *__restrict__ l, const double *__restrict__ m,
                                                          const double *__restrict__ n, const double *__restrict__ w,
                                                          int64_t first, int64_t nvec, double *__restrict__ partial)
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock, 2) void focus_step_kernel(Cols c, const dou
 }
 
 template <int V, bool HASW>
-__global__ __launch_bounds__(kBlock) void central_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(kBlock, 2) void central_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                          const double *__restrict__ w, int64_t first, int64_t nvec,
                                                          double cx, double cy, double *__restrict__ partial)
 {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void central_kernel(const double *__restric
 
 // rows[0..nrows) of K doubles -> out[K]; `accumulate` adds to what is already there (tail launch)
 template <int K>
-__global__ __launch_bounds__(kBlock) void fold_rows_kernel(const double *__restrict__ rows, int nrows,
+__global__ __launch_bounds__(kBlock, 2) void fold_rows_kernel(const double *__restrict__ rows, int nrows,
                                                            double *__restrict__ out, int accumulate)
 {
     double acc[K];

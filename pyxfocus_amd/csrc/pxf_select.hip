@@ -46,7 +46,7 @@ __device__ __forceinline__ double value_of(unsigned long long key)
 }
 
 template <int NK>
-__global__ __launch_bounds__(kBlock) void sel_hist_kernel(const double *__restrict__ v, int64_t num,
+__global__ __launch_bounds__(kBlock, 2) void sel_hist_kernel(const double *__restrict__ v, int64_t num,
                                                           SelState *__restrict__ st, int pass,
                                                           const unsigned long long *__restrict__ count_dev = nullptr)
 {
@@ -192,7 +192,7 @@ __device__ __forceinline__ double fs_radius(double x, double y, double cx, doubl
     return sqrt(dx * dx + dy * dy);
 }
 
-__global__ __launch_bounds__(kBlock) void fs_sample_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(kBlock, 2) void fs_sample_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                            double cx, double cy, int mode, int64_t num, int nsamp,
                                                            double *__restrict__ out)
 {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void fs_sample_kernel(const double *__restr
 
 constexpr int kFsStage = 2048;  // candidates staged per workgroup in LDS between flushes
 
-__global__ __launch_bounds__(kBlock) void fs_collect_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(kBlock, 2) void fs_collect_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                             double cx, double cy, int mode, int64_t num,
                                                             FastSelState *__restrict__ fs, double *__restrict__ cand,
                                                             long long cap)
@@ -312,7 +312,7 @@ __device__ __forceinline__ long long signed_key(unsigned long long key) { return
 __device__ __forceinline__ unsigned long long unsigned_key(long long sk) { return (unsigned long long)sk ^ 0x8000000000000000ull; }
 
 template <int NK>
-__global__ __launch_bounds__(kBlock) void wsel_hist_kernel(const double *__restrict__ v, const double *__restrict__ w,
+__global__ __launch_bounds__(kBlock, 2) void wsel_hist_kernel(const double *__restrict__ v, const double *__restrict__ w,
                                                            int64_t num, WSelState *__restrict__ st, int pass)
 {
     __shared__ double s_hist[NK][kSelBins];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64) void wsel_pick_kernel(WSelState *__restrict__ s
 }
 
 template <int NK>
-__global__ __launch_bounds__(kBlock) void wsel_neighbors_kernel(const double *__restrict__ v, int64_t num,
+__global__ __launch_bounds__(kBlock, 2) void wsel_neighbors_kernel(const double *__restrict__ v, int64_t num,
                                                                 WSelState *__restrict__ st)
 {
     unsigned long long keyk[NK];

@@ -155,7 +155,7 @@ __device__ __forceinline__ void make_ray(const SrcParams &q, uint64_t gidx, doub
 }
 
 template <int KIND, int V, bool NT>
-__global__ __launch_bounds__(kBlock) void source_kernel(Cols cols, int64_t first, int64_t nvec, SrcParams q)
+__global__ __launch_bounds__(kBlock, 2) void source_kernel(Cols cols, int64_t first, int64_t nvec, SrcParams q)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void source_kernel(Cols cols, int64_t first
 // segmented source: ray i belongs to segment i / rps and takes its four parameters from a device
 // table [nseg][4] (consecutive rays read the same 32 bytes: one L1 line per wave)
 template <int KIND, bool NT>
-__global__ __launch_bounds__(kBlock) void source_seg_kernel(Cols cols, int64_t nvec, SrcParams q,
+__global__ __launch_bounds__(kBlock, 2) void source_seg_kernel(Cols cols, int64_t nvec, SrcParams q,
                                                             const double *__restrict__ table, int64_t rps)
 {
     constexpr int V = 2;

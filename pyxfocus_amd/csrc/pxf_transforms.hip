@@ -15,7 +15,7 @@ struct Mat34 {
 };
 
 template <int V, int NVEC>
-__global__ __launch_bounds__(kBlock) void applyt_kernel(Cols in, Cols out, int64_t first, int64_t nvec,
+__global__ __launch_bounds__(kBlock, 2) void applyt_kernel(Cols in, Cols out, int64_t first, int64_t nvec,
                                                         Mat34 mpos, Mat34 mdir)
 {
     const int64_t stride = (int64_t)gridDim.x * kBlock;

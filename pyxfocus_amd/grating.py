@@ -65,7 +65,13 @@ def fanArray(rays, hubdist, length, ang, dpermm, order, wave, thr=.001, coords=N
 
     which costs a dozen passes over the bundle and a host synchronisation per grating row (~226 rows for the
     Arcus petal); here every ray walks the fan in registers with the same device code (two launches).
-    Returns i, the number of rows walked (the caller undoes `ang * i` of rotation, sector.py:718)."""
+    Returns i, the number of rows walked (the caller undoes `ang * i` of rotation, sector.py:718).
+
+    A ray that never lands on a grating (a dead ray: zeroed or NaN direction cosines from an upstream miss) makes
+    the reference's loop spin forever; here it raises RuntimeError after `maxiter` rows -- and by then the search has
+    rotated every ray in place by its own number of rows: THE BUNDLE IS UNDEFINED after that error (and `coords`
+    is not updated).  Vignette dead rays first (`transformations.vignette(rays)`), as the reference's drivers do
+    before their grating stage (sector.py:629-634), or trace on a copy."""
     import ctypes as C
 
     import torch
@@ -77,16 +83,17 @@ def fanArray(rays, hubdist, length, ang, dpermm, order, wave, thr=.001, coords=N
     cols = list(rays[1:10])
     num, dev = native._check_cols(cols, "fanArray")
     it_hit = torch.empty(max(num, 1), dtype=torch.int32, device=dev)
-    scal = torch.zeros(4, dtype=torch.int32, device=dev)           # [imax | pad | nmiss (uint64)]
+    scal = torch.zeros(2, dtype=torch.int64, device=dev)           # [imax (low int32) | nmiss (uint64)]
     ptrs = (C.c_void_p * 10)(None, *[t.data_ptr() for t in cols])
     h, st = _lib.lib(), native._stream(dev)
     with torch.cuda.device(dev):
         _lib.check(h.pxf_fan_search(ptrs, num, float(hubdist), float(length), float(ang), float(thr), int(maxiter),
-                                    it_hit.data_ptr(), scal.data_ptr(), scal[2:].data_ptr(), st), "pxf_fan_search")
-        imax, _, miss_lo, miss_hi = [int(v) for v in scal.tolist()]          # the one sync: the row count is data-dependent
-        if miss_lo or miss_hi:
-            raise RuntimeError("fanArray: %d rays never reached a grating within %d rows"
-                               % (miss_lo + (miss_hi << 32), maxiter))
+                                    it_hit.data_ptr(), scal.data_ptr(), scal[1:].data_ptr(), st), "pxf_fan_search")
+        imax, nmiss = [int(v) for v in scal.tolist()]                         # the one sync: the row count is data-dependent
+        imax &= 0xffffffff
+        if nmiss:
+            raise RuntimeError("fanArray: %d rays never reached a grating within %d rows; the bundle is undefined now "
+                               "(vignette dead rays before the grating stage)" % (nmiss, maxiter))
         _lib.check(h.pxf_fan_finish(ptrs, num, float(ang), float(dpermm), float(order), float(wave), it_hit.data_ptr(),
                                     imax, st), "pxf_fan_finish")
     if coords is not None:

@@ -681,3 +681,24 @@ def test_frame_angles_where_libm_sincos_differs_from_sin_and_cos(port):
         got = to_host(t)
         for k in ALLCOLS:
             assert bits_equal(got[k], want[k]).all(), ("spocone", tg, k)
+
+
+def test_box_libm_is_the_one_the_kernels_restate():
+    """The W-S kernels restate glibc 2.35's x86-64 sincos / tan / atan2 (pxf_libm_match.h) and the frame changes take
+    their host sin/cos from `sincos`; the oracle the GPU tests compare with runs on THIS box's C library.  If the box
+    carries another libm (glibc picks these routines per CPU and per version), say THAT -- instead of letting the W-S
+    parity tests fail a quantum off with no hint why.  (The same checks run as CPU tests in tests/test_host.py; this
+    runs them on the GPU box, once per suite.)"""
+    import json
+    import os
+    import platform
+    import test_host
+    prov = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "PROVENANCE.json")))
+    here = " ".join(platform.libc_ver())
+    try:
+        test_host.test_ws_secondary_cos_beta_matches_libm_bitwise()
+        test_host.test_ws_back_sincos_atan2_matches_libm_bitwise()
+    except AssertionError as e:
+        pytest.fail("this box's C library (%s) does not compute sincos/tan/atan2 like the one the kernels restate and the "
+                    "fixtures were made with (%s on %s): Wolter-Schwarzschild parity (tests below) is expected to be a "
+                    "quantum (5e-9 mm) off for a few rays -- %s" % (here, prov["libc"], prov["cpu"], str(e)[:300]))
