@@ -112,6 +112,14 @@ __device__ __forceinline__ void fan_rotate_full(TransformOp<false> rot, int grou
     rot.groups = groups;
     rot.apply<1>(r, sel, wm);
 }
+// what a flat leaves behind besides x, y (surfacesf.f95:12-15): z = +0, normal (0, 0, 1)
+__device__ __forceinline__ void fan_materialise(double *q)
+{
+    q[Z] = 0.;
+    q[UX] = 0.;
+    q[UY] = 0.;
+    q[UZ] = 1.;
+}
 __device__ __forceinline__ void load9(const Cols &c, int64_t i, Ray &r)
 {
 #pragma unroll
@@ -132,7 +140,7 @@ __device__ __forceinline__ void store9(const Cols &c, int64_t i, const Ray &r)
 //                       only ever rotates, so ONE window test before the loop covers it for every round (above)
 //     the normal: NOT rotated -- the next flat overwrites it; only a round that turns out grazing needs the rotated
 //                 (0, 0, 1), and gets it from the full arithmetic then
-//     flat: the shared FlatOp::advance, position only
+//     flat: the shared FlatOp::distance / move_xy on (x, y, z1); z = +0 and the normal stay implicit
 // 10 multiplies / adds and 3 class tests where the generic round has 39 and 15.  Every other state (first round, after
 // a grazing round, any special value anywhere) takes the generic round, which is the full reference arithmetic.
 __global__ __launch_bounds__(kBlock, 2) void fan_search_kernel(Cols c, int64_t num, FanGeom g, int32_t *__restrict__ it_hit,
@@ -146,51 +154,77 @@ __global__ __launch_bounds__(kBlock, 2) void fan_search_kernel(Cols c, int64_t n
         load9(c, i, r[0]);
         double *q = r[0].c;
         // round 0: the bundle as it arrives
-        bool flat_prev = fan_not_grazing(q[N], g);   // "z = +0 and normal = (0,0,1) as the last flat left them"
-        if (flat_prev) {
-            FlatOp<false>::advance(q);
-            q[UX] = 0.;
-            q[UY] = 0.;
-            q[UZ] = 1.;
-        }
+        // flat_prev: "the ray has just been through a flat": z = +0 and normal = (0, 0, 1) -- IMPLICITLY: the registers
+        // of z and of the normal are not kept up to date in that state (fan_materialise writes them when they are needed)
+        bool flat_prev = fan_not_grazing(q[N], g);
+        if (flat_prev) FlatOp<false>::move_xy(q, FlatOp<false>::distance(q[Z], q[N]));
         bool hit = fan_in_range(q, g);
         int it = 0;
         // l never changes in the search and (m, n) only rotates: one test before the loop covers every round
         const bool dir_plain = rot_window && !fan_special(q[L]) && fan_pair_window(q[M], q[N]);
         while (!hit && it < g.cap) {
             it++;
-            bool normal_pending = false;             // the normal still has to go through this round's frame change
-            bool done = false;
+            // The rays of a wave are neighbours in the bundle and walk the fan alike (97.7 % lane utilisation on the Arcus
+            // petal, tools/dev/fan_divergence.py), and nearly every round is the plain one for all of them.  The plain
+            // round is therefore tried for the WAVE: if every active lane qualifies (one ballot), it runs as straight-line
+            // code with no per-lane branching -- the per-lane form below spends as many scalar instructions on exec-mask
+            // bookkeeping as it spends vector instructions on arithmetic (PMC: 44 SALU + 48 VALU per round, 66 % VALU issue).
+            {
+                const double y1 = cx * q[Y], zz1 = sx * q[Y];
+                double l1 = q[L], m1 = q[M], n1 = q[N];
+                rotv<1>(l1, m1, n1, cx, sx);
+                const bool plain = flat_prev && dir_plain &&
+                                   !((int)fan_special(q[X]) | (int)fan_special_or_zero(y1) | (int)fan_special_or_zero(zz1)) &&
+                                   fabs(n1) > g.s_hi;                              // not grazing, decided without the asin
+                if (__builtin_amdgcn_ballot_w64(plain) == __builtin_amdgcn_ballot_w64(true)) {
+                    q[Y] = y1;
+                    q[M] = m1;
+                    q[N] = n1;
+                    FlatOp<false>::move_xy(q, FlatOp<false>::distance(zz1, n1));
+                    hit = fan_in_range(q, g);
+                    continue;
+                }
+            }
+            bool hot = false;
+            double z1 = 0.;
             if (flat_prev && dir_plain) {
-                const double y1 = cx * q[Y], z1 = sx * q[Y];
+                const double y1 = cx * q[Y];
+                z1 = sx * q[Y];
                 const int bad = (int)fan_special(q[X]) | (int)fan_special_or_zero(y1) | (int)fan_special_or_zero(z1);
                 if (!bad) {
                     q[Y] = y1;
-                    q[Z] = z1;
                     rotv<1>(q[L], q[M], q[N], cx, sx);
-                    normal_pending = true;
-                    done = true;
+                    hot = true;
                 }
             }
-            if (!done) fan_rotate_full(g.rot, 7, r);
+            if (!hot) {
+                if (flat_prev) fan_materialise(q);
+                fan_rotate_full(g.rot, 7, r);
+                z1 = q[Z];
+            }
             if (fan_not_grazing(q[N], g)) {
-                FlatOp<false>::advance(q);
-                q[UX] = 0.;
-                q[UY] = 0.;
-                q[UZ] = 1.;
+                FlatOp<false>::move_xy(q, FlatOp<false>::distance(z1, q[N]));
                 flat_prev = true;
             } else {
-                if (normal_pending) fan_rotate_full(g.rot, 4, r);   // (0,0,1) through this round's frame change
+                if (hot) {   // a grazing round after a flat: z as rotated, and (0,0,1) through this round's frame change
+                    fan_materialise(q);
+                    fan_rotate_full(g.rot, 4, r);
+                    q[Z] = z1;
+                }
                 flat_prev = false;
             }
             hit = fan_in_range(q, g);
         }
+        if (flat_prev) fan_materialise(q);
         store9(c, i, r[0]);
         it_hit[i] = hit ? it : -1;
-        if (hit)
-            atomicMax(imax, it);
-        else
+        // the bundle's round count: every wave would send one atomic to the SAME address (1.6e7 of them at 1e9 rays);
+        // a plain read first -- the value only ever grows, so a stale one merely lets a few redundant atomics through
+        if (hit) {
+            if (it > __atomic_load_n(imax, __ATOMIC_RELAXED)) atomicMax(imax, it);
+        } else {
             atomicAdd(nmiss, 1ull);
+        }
     }
 }
 
@@ -217,6 +251,7 @@ __global__ __launch_bounds__(kBlock, 2) void fan_finish_kernel(Cols c, int64_t n
         const bool plain = rot_window && !((int)fan_special(q[X]) | (int)fan_special(q[L]) | (int)fan_special(q[UX])) &&
                            fan_pair_window(q[Y], q[Z]) && fan_pair_window(q[M], q[N]) && fan_pair_window(q[UY], q[UZ]);
         if (plain) {
+#pragma unroll 2
             for (int j = it + 1; j <= imax; j++) {
                 rotv<1>(q[X], q[Y], q[Z], rot.cx, rot.sx);
                 rotv<1>(q[L], q[M], q[N], rot.cx, rot.sx);

@@ -88,6 +88,48 @@ struct LLData : LLParams {
     double za[kLLRows], zb[kLLRows];  // (2n+3)/(n+2), (n+1)/(n+2): P_{n+2} = za_n x P_{n+1} - zb_n P_n
 };
 
+// R consecutive axial orders of the any-order form (ll_trace, KTMAX < 0): s0[r] = sum_j C[i+r][j] P_j(t),
+// s1[r] = sum_j C[i+r][j] P'_j(t) from one run of the t-recurrence, then folded into the three sums with
+// P_{i+r}(z), P'_{i+r}(z); the z-recurrence state (pz0 = P_i, pz1 = P_{i+1}, dz0, dz1) advances by R orders.
+// `crow` points into the kernel-argument segment (wave-uniform: scalar loads), ra / rb into the LDS table.
+template <int R>
+__device__ __forceinline__ void ll_rows(const double *__restrict__ crow, int nt, double tc, double zc,
+                                        const double *__restrict__ ra, const double *__restrict__ rb, int i,
+                                        double &pz0, double &pz1, double &dz0, double &dz1, double &add, double &addt,
+                                        double &addzz)
+{
+    double s0[R], s1[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) s0[r] = s1[r] = 0.;
+    double pt0 = 1., pt1 = tc, dt0 = 0., dt1 = 1.;
+    for (int j = 0; j < nt; j++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double cij = crow[r * nt + j];
+            s0[r] = __builtin_fma(cij, pt0, s0[r]);   // tolerance-parity surface: FMA allowed here
+            s1[r] = __builtin_fma(cij, dt0, s1[r]);
+        }
+        const double pn = __builtin_fma(ra[j] * tc, pt1, -(rb[j] * pt0));   // P_{j+2}
+        const double dn = __builtin_fma((double)(2 * j + 3), pt1, dt0);     // P'_{j+2}
+        pt0 = pt1;
+        pt1 = pn;
+        dt0 = dt1;
+        dt1 = dn;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        add = __builtin_fma(pz0, s0[r], add);
+        addt = __builtin_fma(pz0, s1[r], addt);
+        addzz = __builtin_fma(dz0, s0[r], addzz);
+        const double pn = __builtin_fma(ra[i + r] * zc, pz1, -(rb[i + r] * pz0));
+        const double dn = __builtin_fma((double)(2 * (i + r) + 3), pz1, dz0);
+        pz0 = pz1;
+        pz1 = pn;
+        dz0 = dz1;
+        dz1 = dn;
+    }
+}
+
 // KIND: 0 primary (:220-288), 1 secondary (:293-379), 2 ellipsoid (:643-718).
 // KTMAX >= 0 ("register form"): the azimuthal orders are known to be <= KTMAX.  The host pads the matrix to
 // KTMAX+1 columns and an even number of rows with zeros, so the double sum has NO data-dependent control
@@ -96,7 +138,7 @@ struct LLData : LLParams {
 // wave-uniform SCALAR loads (an SGPR pair is one operand of v_fma_f64) -- no LDS traffic at all -- and two
 // axial orders run per trip as four independent FMA chains.  (Round 1-2 staged the matrix in LDS: four SIMDs
 // reading one ds_read_b64 per two FMAs made the LDS pipe, not the fp64 pipe, the bound: 54 % VALU issue.)
-// KTMAX < 0: any order; matrix in LDS, the t-recurrence regenerated for every axial order.
+// KTMAX < 0: any order; four axial orders share one run of the t-recurrence (ll_rows), coefficients by scalar loads.
 template <int KIND, int KTMAX>
 __device__ __forceinline__ void ll_trace(const LLParams &P, const double *__restrict__ cmat,
                                          const double *__restrict__ za, const double *__restrict__ zb, double *c,
@@ -162,32 +204,29 @@ __device__ __forceinline__ void ll_trace(const LLParams &P, const double *__rest
             addt = tin ? addt : 0.;
             addzz = zin ? addzz : 0.;
         } else {
-            const double *__restrict__ cm = cmat, *__restrict__ ra = za, *__restrict__ rb = zb;   // LDS (generic form)
-            for (int i = 0; i <= P.ka; i++) {
-                const double Pz = pz0, dPz = zin ? dz0 : 0.;
-                double s0 = 0., s1 = 0.;  // sum_j C_ij P_j(t), sum_j C_ij P'_j(t)
-                double pt0 = 1., pt1 = tc, dt0 = 0., dt1 = 1.;
-                for (int j = 0; j <= P.kt; j++) {
-                    const double cij = cm[i * (P.kt + 1) + j];
-                    s0 += cij * pt0;
-                    s1 += cij * (tin ? dt0 : 0.);
-                    const double pn = ra[j] * tc * pt1 - rb[j] * pt0;  // P_{j+2}
-                    const double dn = dt0 + (2 * j + 3) * pt1;                            // P'_{j+2}
-                    pt0 = pt1;
-                    pt1 = pn;
-                    dt0 = dt1;
-                    dt1 = dn;
+            // Any order.  R axial orders at a time (4, then 2, then 1 for what is left) share ONE run of the
+            // t-recurrence: per azimuthal order 2 FMAs per coefficient plus the recurrence step (3 FMAs and a multiply,
+            // its two ratios from the LDS table), instead of regenerating P_j(t), P'_j(t) for every coefficient.  The
+            // coefficients come from the kernel-argument segment through scalar loads (wave-uniform addresses), as in
+            // the register form; P'(t) = 0 outside [-1, 1] enters linearly and is applied once after the loops.
+            const double *__restrict__ ra = za, *__restrict__ rb = zb;   // LDS: (2n+3)/(n+2), (n+1)/(n+2)
+            const int nt = P.kt + 1;
+            int i = 0;
+            while (i <= P.ka) {
+                const int left = P.ka + 1 - i;
+                if (left >= 4) {
+                    ll_rows<4>(cmat + i * nt, nt, tc, zc, ra, rb, i, pz0, pz1, dz0, dz1, add, addt, addzz);
+                    i += 4;
+                } else if (left >= 2) {
+                    ll_rows<2>(cmat + i * nt, nt, tc, zc, ra, rb, i, pz0, pz1, dz0, dz1, add, addt, addzz);
+                    i += 2;
+                } else {
+                    ll_rows<1>(cmat + i * nt, nt, tc, zc, ra, rb, i, pz0, pz1, dz0, dz1, add, addt, addzz);
+                    i += 1;
                 }
-                add += Pz * s0;
-                addt += Pz * s1;
-                addzz += dPz * s0;
-                const double pn = ra[i] * zc * pz1 - rb[i] * pz0;
-                const double dn = dz0 + (2 * i + 3) * pz1;
-                pz0 = pz1;
-                pz1 = pn;
-                dz0 = dz1;
-                dz1 = dn;
             }
+            addt = tin ? addt : 0.;
+            addzz = zin ? addzz : 0.;
         }
         const double r2 = y * y + x * x;
         const double ir2 = 1. / r2;
@@ -238,21 +277,19 @@ struct LLOp : LLData {
     static constexpr unsigned RD = POS | DIR;
     static constexpr unsigned WR = POS | NRM;
 
-    // LDS (generic form only): [0,kLLMax) the matrix C, then the recurrence coefficients a_n, b_n
+    // LDS (any-order form only): the recurrence ratios a_n = (2n+3)/(n+2), b_n = (n+1)/(n+2) for n < kLLMax
     __device__ __forceinline__ double *lds() const
     {
-        __shared__ double s_c[3 * kLLMax];
+        __shared__ double s_c[2 * kLLMax];
         return s_c;
     }
     __device__ __forceinline__ void prologue() const
     {
         if constexpr (KTMAX < 0) {
             double *s = lds();
-            const int nn = (ka + 1) * (kt + 1);
-            for (int i = threadIdx.x; i < nn; i += kBlock) s[i] = cmat[i];
             for (int i = threadIdx.x; i < kLLMax; i += kBlock) {
-                s[kLLMax + i] = (double)(2 * i + 3) / (double)(i + 2);
-                s[2 * kLLMax + i] = (double)(i + 1) / (double)(i + 2);
+                s[i] = (double)(2 * i + 3) / (double)(i + 2);
+                s[kLLMax + i] = (double)(i + 1) / (double)(i + 2);
             }
             __syncthreads();
         }
@@ -263,7 +300,7 @@ struct LLOp : LLData {
     {
         if constexpr (KTMAX < 0) {
             const double *s = lds();
-            ll_trace<KIND, KTMAX>(*this, s, s + kLLMax, s + 2 * kLLMax, r[0].c, sel[0]);
+            ll_trace<KIND, KTMAX>(*this, cmat, s, s + kLLMax, r[0].c, sel[0]);
         } else {
             ll_trace<KIND, KTMAX>(*this, cmat, za, zb, r[0].c, sel[0]);
         }

@@ -23,14 +23,22 @@ struct FlatOp {
     double nr;
     // the propagation itself (position only); returns the distance.  Shared with the fanned-grating kernels
     // (pxf_fan.hip), which keep the normal implicit while a ray walks the fan.
-    static __device__ __forceinline__ double advance(double *c)
+    static __device__ __forceinline__ double distance(double z, double n)
     {
         // `delta` is implicitly REAL*4 in the reference: round the distance to fp32
-        const float delta = (float)(-c[Z] / c[N]);
-        const double dd = (double)delta;
-        c[Z] = 0.;
+        const float delta = (float)(-z / n);
+        return (double)delta;
+    }
+    static __device__ __forceinline__ void move_xy(double *c, double dd)
+    {
         c[X] = c[X] + dd * c[L];
         c[Y] = c[Y] + dd * c[M];
+    }
+    static __device__ __forceinline__ double advance(double *c)
+    {
+        const double dd = distance(c[Z], c[N]);
+        c[Z] = 0.;
+        move_xy(c, dd);
         return dd;
     }
     template <int V>

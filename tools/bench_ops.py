@@ -84,6 +84,17 @@ def main():
             mm.append(m_)
         n_ += 1
     nn, mm = np.array(nn[:36]), np.array(mm[:36])
+
+    def zern_full(order):                  # every (n, m) up to radial order `order`: 66 terms at 10, 136 at 15
+        n2, m2 = [], []
+        for n__ in range(order + 1):
+            for m__ in range(-n__, n__ + 1, 2):
+                n2.append(n__)
+                m2.append(m__)
+        c2 = np.random.default_rng(order).normal(0, 1e-3, len(n2)) / (1. + np.array(n2))
+        c2[0] = 0.
+        return c2, np.array(n2), np.array(m2)
+    z10, z15 = zern_full(10), zern_full(15)
     llc = np.array([1e-4, 5e-5, 2e-5])
     lla = np.array([2, 3, 4])
     llz = np.array([0, 1, 2])
@@ -163,6 +174,10 @@ def main():
          lambda r: surf.legSurf(r, 25., 25., 1, np.array([1e-4, 2e-5, 1e-5]), np.array([1, 2, 0]),
                                 np.array([0, 1, 2])), 64),
         ("zernsurf36", lambda: beam(rad=50., z=10.), lambda r: surf.zernsurf(r, zc, 50., rorder=nn, aorder=mm), 96),
+        ("zernsurfN10 (66 terms, radial order 10)", lambda: beam(rad=50., z=10.),
+         lambda r: surf.zernsurf(r, z10[0], 50., rorder=z10[1], aorder=z10[2]), 96),
+        ("zernsurfN15 (136 terms, radial order 15)", lambda: beam(rad=50., z=10.),
+         lambda r: surf.zernsurf(r, z15[0], 50., rorder=z15[1], aorder=z15[2]), 96),
         ("zernconic36", lambda: beam(rad=50., z=10.),
          lambda r: surf.zernconic(r, 5000., -1., zc, 50., rorder=nn, aorder=mm), 96),
         ("zernphase36", normal_beam, lambda r: surf.zernphase(r, zc, 50., 1e-3, rorder=nn, aorder=mm), 80),

@@ -42,18 +42,30 @@ def main():
     scal = torch.zeros(4, dtype=torch.int32, device=dev)
     ptrs = (C.c_void_p * 10)(None, *[t.data_ptr() for t in cols])
     h = _lib.lib()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ev[0].record()
-    _lib.check(h.pxf_fan_search(ptrs, num, hubdist, A.GRATLEN, ang, .001, 100000, it_hit.data_ptr(), scal.data_ptr(),
-                                scal[2:].data_ptr(), native._stream(dev)), "pxf_fan_search")
-    ev[1].record()
-    torch.cuda.synchronize()
+    keep = [t.clone() for t in cols]
+    best = [1e30, 1e30]
+    for rep in range(3):                              # (the first repetition carries the code-object load)
+        for t, k in zip(cols, keep):
+            t.copy_(k)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        _lib.check(h.pxf_fan_search(ptrs, num, hubdist, A.GRATLEN, ang, .001, 100000, it_hit.data_ptr(), scal.data_ptr(),
+                                    scal[2:].data_ptr(), native._stream(dev)), "pxf_fan_search")
+        ev[1].record()
+        torch.cuda.synchronize()
+        imax_ = int(scal[0])
+        _lib.check(h.pxf_fan_finish(ptrs, num, ang, 160. / hubdist, -3., 2.4, it_hit.data_ptr(), imax_,
+                                    native._stream(dev)), "pxf_fan_finish")
+        ev[2].record()
+        torch.cuda.synchronize()
+        best = [min(best[0], ev[0].elapsed_time(ev[1])), min(best[1], ev[1].elapsed_time(ev[2]))]
+    del keep
     it = it_hit.cpu().numpy().astype(np.int64)
     imax = int(scal[0])
     full = it[:num // 64 * 64].reshape(-1, 64)
     search_rounds = full + 1                       # round 0 counts
     finish_rounds = imax - full
-    out = {"rays": num, "imax": imax, "search_ms": ev[0].elapsed_time(ev[1]),
+    out = {"rays": num, "imax": imax, "search_ms": best[0], "finish_ms": best[1],
            "mean_rounds_search": float(search_rounds.mean()), "mean_of_wave_max_search": float(search_rounds.max(1).mean()),
            "lane_utilisation_search": float(search_rounds.sum() / (64 * search_rounds.max(1).sum())),
            "lane_utilisation_finish": float(finish_rounds.sum() / max(1, 64 * finish_rounds.max(1).sum())),

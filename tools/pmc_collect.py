@@ -245,7 +245,7 @@ def main():
                     "BASELINE config 5 share (Arcus petal: segmented source, segmented SPO-pair program exact + fast, grating "
                     "program, focusY), %g rays; the stacked-grating while loop runs on 1e8 rays." % crays),
         "ops": (py + [os.path.join(ROOT, "tools", "bench_ops.py"), "--rays", "1e8", "--reps", "3", "--only",
-                      "woltersine,primaryLL,secondaryLL,wsPrimary,wsSecondary,wsPrimaryB,wsSecondaryB,zernsurf36,zernconic36,LL,W-S"],
+                      "woltersine,primaryLL,secondaryLL,wsPrimary,wsSecondary,wsPrimaryB,wsSecondaryB,zernsurf36,zernsurfN10,zernsurfN15,zernconic36,LL,W-S"],
                 int(1e8), [], "Legendre-Legendre / Wolter-Schwarzschild / woltersine / Zernike kernels one by one "
                 "(tools/bench_ops.py, 1e8 rays)."),
     }
