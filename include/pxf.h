@@ -50,6 +50,11 @@ int pxf_last_hip_error(void); /* hipError_t of the last failing HIP call on this
  * PXF_ENODEV otherwise (no device, or another architecture).  Every launch makes the same check and returns
  * PXF_ENODEV itself; this entry lets a binding ask up front.  Cached per device ordinal. */
 int pxf_device_check(void);
+/* Self-test of the shared-reciprocal divisions inside the bit-exact kernels (csrc/pxf_exactdiv.h): `ntuples` random
+ * operand tuples -- exponents across and around the fast path's window, the whole fp64 range, zeros, denormals,
+ * infinities, NaNs -- through every such routine and through `/`; *mismatches_dev (device uint64) receives the number
+ * of results that differ in any bit (NaN == NaN).  Must be 0.  Run by the GPU test suite. */
+int pxf_selftest_exact_division(int64_t ntuples, uint64_t seed, uint64_t *mismatches_dev, pxf_stream_t stream);
 
 /* ---- surfacesf.f95 --------------------------------------------------------------------- */
 

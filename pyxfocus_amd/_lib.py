@@ -29,6 +29,7 @@ _SIGS = {
     "pxf_strerror": [C.c_int],
     "pxf_last_hip_error": [],
     "pxf_device_check": [],
+    "pxf_selftest_exact_division": [_i64, _u64, _P, _P],
     "pxf_flat": [_P] * 9 + [_i64, _P, _P],
     "pxf_flatopd": [_P] * 10 + [_i64, _d, _P, _P],
     "pxf_conic": [_P] * 9 + [_i64, _d, _d, _P, _P],

@@ -9,6 +9,7 @@
 #pragma once
 #include <math.h>
 
+#include "pxf_exactdiv.h"
 #include "pxf_kernel.h"
 
 namespace pxf {
@@ -172,9 +173,7 @@ struct WolterPrimaryOp {
 #pragma unroll
         for (int k = 0; k < V; k++) {
             const double Fp = sqrt(Fx[k] * Fx[k] + Fy[k] * Fy[k] + Fz * Fz);
-            r[k].c[UX] = Fx[k] / Fp;
-            r[k].c[UY] = Fy[k] / Fp;
-            r[k].c[UZ] = Fz / Fp;
+            div3_exact(Fx[k], Fy[k], Fz, Fp, r[k].c[UX], r[k].c[UY], r[k].c[UZ]);   // == Fx/Fp, Fy/Fp, Fz/Fp
             wm[k] = WR;
         }
     }
@@ -224,9 +223,7 @@ struct WolterSecondaryOp {
 #pragma unroll
         for (int k = 0; k < V; k++) {
             const double Fp = sqrt(Fx[k] * Fx[k] + Fy[k] * Fy[k] + Fz[k] * Fz[k]);
-            r[k].c[UX] = Fx[k] / Fp;
-            r[k].c[UY] = Fy[k] / Fp;
-            r[k].c[UZ] = Fz[k] / Fp;
+            div3_exact(Fx[k], Fy[k], Fz[k], Fp, r[k].c[UX], r[k].c[UY], r[k].c[UZ]);   // == Fx/Fp, Fy/Fp, Fz/Fp
             wm[k] = WR;
         }
     }
@@ -255,16 +252,18 @@ struct SpoConeOp {
             const double det = Bq * Bq - 4 * A * C;
             if (det >= 0) {
                 const double sq = sqrt(det);
-                double t1 = (-Bq + sq) / (2 * A);
-                const double t2 = (-Bq - sq) / (2 * A);
+                double t1, t2;
+                div2_exact(-Bq + sq, -Bq - sq, 2 * A, t1, t2);   // == (-Bq + sq) / (2 A), (-Bq - sq) / (2 A)
                 if (fabs(t2) < fabs(t1)) t1 = t2;
                 const double xn = x + t1 * l, yn = y + t1 * m;
                 c[X] = xn;
                 c[Y] = yn;
                 c[Z] = z + t1 * n;
                 const double rr = sqrt(xn * xn + yn * yn);
-                c[UX] = -xn / rr * ctg;
-                c[UY] = -yn / rr * ctg;
+                double ax, ay;
+                div2_exact(-xn, -yn, rr, ax, ay);                // == -xn / rr, -yn / rr
+                c[UX] = ax * ctg;
+                c[UY] = ay * ctg;
                 c[UZ] = stg;
                 wm[k] = POS | NRM;
             } else {

@@ -9,6 +9,7 @@
 #pragma once
 #include <math.h>
 
+#include "pxf_exactdiv.h"
 #include "pxf_kernel.h"
 
 namespace pxf {
@@ -171,15 +172,17 @@ struct RadgratOp {
         for (int k = 0; k < V; k++) {
             double *c = r[k].c;
             const double x = c[X], y = c[Y];
-            const double sn = WAVECOL ? y / fabs(y) : c[N] / fabs(c[N]);
+            const double sn = unit_sign_exact(WAVECOL ? y : c[N]);   // == y/|y|, n/|n|
             const double w = WAVECOL ? c[AUX] : wave;
             const double rho = sqrt(y * y + x * x);
             const double d = dpermm * rho;
-            const double cphi = y / rho, sphi = x / rho;
+            double cphi, sphi, dl, dm;
+            div2_exact(y, x, rho, cphi, sphi);                       // == y/rho, x/rho
             const double syaw = -(S * cphi + C * sphi);
             const double cyaw = C * cphi - S * sphi;
-            c[L] = c[L] + syaw * order * w / d;
-            c[M] = c[M] - cyaw * order * w / d;
+            div2_exact(syaw * order * w, cyaw * order * w, d, dl, dm);   // == syaw*order*w/d, cyaw*order*w/d
+            c[L] = c[L] + dl;
+            c[M] = c[M] - dm;
             c[N] = sn * sqrt(1. - c[L] * c[L] - c[M] * c[M]);
             wm[k] = WR;
         }

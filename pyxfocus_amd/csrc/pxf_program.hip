@@ -81,8 +81,11 @@ __global__ __launch_bounds__(kBlock, 2) void program_kernel(Cols c, int64_t firs
 // parameters, load / store sets and the transform groups the planner dropped still come from the planned program,
 // so results are the interpreter's bit for bit.  pxf_program_run picks the chain kernel when an unmasked
 // program's code sequence equals one of the lists below.
-template <int CODE, int V, bool NT>
-__device__ __forceinline__ void exec_fixed(int flags, const double *__restrict__ P, const double *__restrict__ aux,
+// `P` is the operation's nine doubles: an ordinary pointer (segmented programs: the workgroup's LDS copy) or a
+// constant-address-space pointer into the kernel-argument segment (program_chain_kernel: scalar loads, issued where the
+// operation starts).
+template <int CODE, int V, bool NT, class PP>
+__device__ __forceinline__ void exec_fixed(int flags, PP P, const double *__restrict__ aux,
                                            int64_t vv, Ray (&r)[V], const bool (&sel)[V])
 {
     if constexpr (CODE == PXF_OP_FLAT) run_op(FlatOp<false>{0.}, r, sel);
@@ -104,11 +107,30 @@ __device__ __forceinline__ void exec_fixed(int flags, const double *__restrict__
     } else static_assert(CODE == PXF_OP_FLAT, "operation not available in a straight-line program");
 }
 
+// the kernel-argument segment of program_chain_kernel(Cols, int64_t, int64_t, Program) as the ABI lays it out
+struct ChainKernarg {
+    Cols c;
+    int64_t first, nvec;
+    Program pg;
+};
+typedef const __attribute__((address_space(4))) char *kernarg_cptr;
+typedef const __attribute__((address_space(4))) double *kernarg_dptr;
+__device__ __forceinline__ kernarg_dptr chain_params(kernarg_cptr ka, int i, double &pin)
+{
+    kernarg_dptr P = (kernarg_dptr)(ka + offsetof(ChainKernarg, pg) + offsetof(Program, op) + (size_t)i * sizeof(ProgOp) +
+                                    offsetof(ProgOp, p));
+    asm volatile("" : "+s"(P), "+v"(pin));
+    return P;
+}
+
+// One workgroup per 256 ray-vectors and NO grid-stride loop (the launch below never caps the grid): with a loop around
+// the body every wave-uniform quantity of the program (load / store bits, transform-group bits, parameter addresses)
+// is loop-invariant, gets hoisted in front of it and is then spilled for want of SGPRs.
 template <int V, bool NT, int... CODES>
 __global__ __launch_bounds__(kBlock, 2) void program_chain_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v < nvec) {
         const int64_t vv = first + v;
         Ray r[V];
 #pragma unroll
@@ -123,8 +145,14 @@ __global__ __launch_bounds__(kBlock, 2) void program_chain_kernel(Cols c, int64_
         bool sel[V];
 #pragma unroll
         for (int k = 0; k < V; k++) sel[k] = true;
+        // Parameters: each operation reads its nine doubles from the kernel-argument segment WHEN IT STARTS.  Left to
+        // itself the compiler hoists every scalar load of the program to the top of the kernel -- 12 operations x 18
+        // SGPRs against a file of ~100 -- and then spills them to VGPR lanes: 240 v_writelane / v_readlane among the
+        // ~1500 vector instructions of the config-3 program, on a kernel that is VALU-bound.  The empty asm ties each
+        // operation's parameter pointer to the ray state the previous operation produced, so its loads cannot move up.
+        const kernarg_cptr ka = (kernarg_cptr)__builtin_amdgcn_kernarg_segment_ptr();
         int i = 0;
-        ((exec_fixed<CODES, V, NT>(pg.op[i].flags, pg.op[i].p, pg.op[i].aux, vv, r, sel), i++), ...);
+        ((exec_fixed<CODES, V, NT>(pg.op[i].flags, chain_params(ka, i, r[0].c[X]), pg.op[i].aux, vv, r, sel), i++), ...);
 #pragma unroll
         for (int col = 0; col < 10; col++) {
             if (pg.store & B(col)) {
@@ -155,8 +183,8 @@ struct Chain {
     template <int V, bool NT>
     static void launch(hipStream_t s, const Cols &c, int64_t first, int64_t nvec, const Program &pg)
     {
-        hipLaunchKernelGGL((program_chain_kernel<V, NT, CODES...>), dim3(grid_for(nvec)), dim3(kBlock), 0, s, c, first,
-                           nvec, pg);
+        hipLaunchKernelGGL((program_chain_kernel<V, NT, CODES...>), dim3((unsigned)((nvec + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, c, first, nvec, pg);
     }
 };
 // BASELINE config 2: transform, wolterprimary, reflect, woltersecondary, reflect, flat

@@ -702,3 +702,22 @@ def test_box_libm_is_the_one_the_kernels_restate():
         pytest.fail("this box's C library (%s) does not compute sincos/tan/atan2 like the one the kernels restate and the "
                     "fixtures were made with (%s on %s): Wolter-Schwarzschild parity (tests below) is expected to be a "
                     "quantum (5e-9 mm) off for a few rays -- %s" % (here, prov["libc"], prov["cpu"], str(e)[:300]))
+
+
+def test_shared_reciprocal_divisions_equal_ieee_division_bitwise():
+    """csrc/pxf_exactdiv.h: the quotients of a surface normal over its length, y/rho and x/rho of a grating, the two
+    roots of a cone over 2A ... share ONE refined reciprocal inside a window of ordinary operands and fall back to `/`
+    outside it.  The library's own self-test draws 2^31 operand tuples (random mantissas; exponents across the window,
+    around both of its edges, over the whole range; zeros, denormals, infinities, NaNs) and compares every routine
+    with `/` as bit patterns: not one result may differ."""
+    import torch
+    from pyxfocus_amd import _lib, native
+    h = _lib.lib()
+    dev = torch.device("cuda", 0)
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    total = 0
+    for seed, n in ((1, 1 << 29), (0xdecafbad, 1 << 30), (2 ** 63 + 12345, 1 << 29)):
+        _lib.check(h.pxf_selftest_exact_division(n, seed, out.data_ptr(), native._stream(dev)), "pxf_selftest_exact_division")
+        assert int(out.item()) == 0, (seed, int(out.item()))
+        total += n
+    assert total == 1 << 31
