@@ -674,6 +674,13 @@ def main():
                 "traffic_source": ("%s @ %s (csrc %s)" % (tr["source"], tr["commit"], csrc_hash())) if tr else
                 "none for the kernel sources of this build (csrc %s): run tools/pmc_collect.py" % csrc_hash(),
                 "algorithmic_bytes_per_launch": dom["bytes_per_ray"] * N, "avg_launch_ms": dom["avg_ms"]}
+    low = min(kern, key=lambda k: k["GBps"])          # the launch furthest from the roof (the longest one is `dom`)
+    roofline["lowest"] = {"kernel": low["kernel"], "launch": low["launch"], "achieved": low["GBps"],
+                          "frac": low["GBps"] / HBM_PEAK_GBS, "avg_launch_ms": low["avg_ms"],
+                          "algorithmic_bytes_per_launch": low["bytes_per_ray"] * N}
+    roofline["durations"] = ("HIP events on the launch stream inside the timed region (an event pair brackets one "
+                             "launch incl. its launch gap); the rocprofv3 kernel-trace durations in profiles/ are "
+                             "4-6 % shorter for the same kernels")
     chain_gbps = float(wl.BYTES["config2"]) * N / (sum(k["avg_ms"] for k in kern) * 1e-3) / 1e9
     # measured device-to-device copy of the same nine columns ("also report against a
     # measured copy kernel") -- what a 9R+9W stream reaches on this GPU with no arithmetic at all

@@ -105,6 +105,7 @@ _SIGS = {
     "pxf_wselect_pick": [_i32, _P, _i32, _P],
     "pxf_wselect_neighbors": [_P, _i64, _i32, _P, _P],
     "pxf_wselect_finish": [_i32, _P, _P, _P],
+    "pxf_griddata": [_P, _P, _P, _i64, _P, _i32, _i32, _d, _d, _d, _d, _DP, _P, _P, _i64, _i32, _P, _P],
     "pxf_southwellbin_workspace_bytes": [_i32, _i32],
     "pxf_southwellbin": [_P, _P, _P, _P, _i64, _d, _P, _P, _P, _i32, _i32, _P, _P],
     "pxf_reconstruct": [_P, _P, _i32, _i32, _d, _d, _P, _P, _i32, _P, _P],

@@ -311,14 +311,77 @@ def hpdY(rays, weights=None):
     return (lo + hi) * .5 * 2.
 
 
-def interpolateVec(rays, I, Nx, Ny, xr=None, yr=None, method='linear', polar=False, interpVec=None):
+def _griddata_device(px, py, pv, qx, qy, method):
+    """scipy.interpolate.griddata((px, py), pv, (qx, qy), method) for method 'nearest' / 'linear' on the device
+    (pxf_griddata): px, py, pv device columns, qx, qy NumPy arrays of one shape; returns a device tensor of that shape."""
+    import ctypes as C
+    if method not in ("nearest", "linear"):
+        raise ValueError("on_device=True supports method='nearest' and 'linear' (cubic is scipy's Clough-Tocher "
+                         "scheme, a global fit over the whole triangulation: use the default host path)")
+    dev = px.device
+    ok = torch.isfinite(px) & torch.isfinite(py)
+    if not bool(ok.all()):
+        px, py, pv = px[ok], py[ok], pv[ok]
+    n = int(px.shape[0])
+    q = np.ascontiguousarray(np.stack([np.asarray(qx, dtype=np.float64).ravel(), np.asarray(qy, dtype=np.float64).ravel()]))
+    m = q.shape[1]
+    out = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+    if n == 0 or m == 0:
+        return out.reshape(np.shape(qx))
+    x0, x1, y0, y1 = float(px.min()), float(px.max()), float(py.min()), float(py.max())
+    g = int(min(4096, max(1, math.ceil(math.sqrt(n / 2.)))))          # ~2 points per cell
+    wx, wy = max(x1 - x0, 1e-300), max(y1 - y0, 1e-300)
+    icx, icy = g / wx, g / wy
+    ci = torch.clamp(((px - x0) * icx).floor().to(torch.int64), 0, g - 1)
+    cj = torch.clamp(((py - y0) * icy).floor().to(torch.int64), 0, g - 1)
+    cid, order = torch.sort(cj * g + ci, stable=True)
+    xs, ys, vs = px[order].contiguous(), py[order].contiguous(), pv.to(torch.float64)[order].contiguous()
+    start = torch.searchsorted(cid, torch.arange(g * g + 1, device=dev, dtype=torch.int64)).to(torch.int32)
+    sup = (C.c_double * 16)(*[float((px * math.cos(2 * math.pi * k / 16) + py * math.sin(2 * math.pi * k / 16)).max())
+                              for k in range(16)])
+    qd = torch.from_numpy(q).to(dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pxf_griddata(xs.data_ptr(), ys.data_ptr(), vs.data_ptr(), n, start.data_ptr(), g, g, x0, y0, icx, icy,
+                                     sup, qd[0].data_ptr(), qd[1].data_ptr(), m, 1 if method == "linear" else 0,
+                                     out.data_ptr(), native._stream(dev))
+    _lib.check(rc, "pxf_griddata")
+    return out.reshape(np.shape(qx))
+
+
+def interpolateVec(rays, I, Nx, Ny, xr=None, yr=None, method='linear', polar=False, interpVec=None, on_device=False):
     """Interpolate ray column `I` (or `interpVec`) onto an Nx x Ny grid spanning the rays' x/y extent
     (analyses.py:189-230).  Returns (grid values, dx, dy) as NumPy objects, like the reference.
 
-    The interpolation itself is `scipy.interpolate.griddata` -- a Delaunay triangulation from a third-party
-    library the reference calls too -- and runs on the HOST on copies of the three columns involved: this is
-    post-processing of a focal plane onto a few thousand grid nodes, not a per-ray hot loop, and sharing the
-    reference's own call is what makes the result identical to it."""
+    Default: the interpolation itself is `scipy.interpolate.griddata` -- a Delaunay triangulation from a third-party
+    library the reference calls too -- on the HOST, on copies of the three columns involved: sharing the reference's
+    own call is what makes the result identical to it.
+
+    ``on_device=True`` (an addition): nothing but the Nx x Ny result leaves the GPU.  Methods 'nearest' and 'linear'
+    (the Delaunay triangle around every grid node found by a per-node simplex walk, pxf_griddata); the values are a
+    device tensor and equal scipy's to the rounding of the barycentric weights for rays in general position (rays on
+    an exact regular grid are co-circular in fours: any Delaunay triangulation of them is as valid as Qhull's pick)."""
+    if on_device:
+        fused.flush()
+        x, y = rays[1], rays[2]
+        v = rays[I] if interpVec is None else interpVec
+        if not isinstance(v, torch.Tensor):
+            v = torch.as_tensor(np.asarray(v, dtype=np.float64), device=x.device)
+        if xr is None:
+            xr = [float(x.min()), float(x.max())]
+            yr = [float(y.min()), float(y.max())]
+        gridx, gridy = np.meshgrid(np.linspace(xr[0], xr[1], Nx), np.linspace(yr[0], yr[1], Ny))
+        dx = np.diff(gridx)[0][0]
+        dy = np.diff(np.transpose(gridy))[0][0]
+        if polar is True:
+            rho_ = torch.sqrt(x ** 2 + y ** 2)
+            rhog = np.sqrt(gridx ** 2 + gridy ** 2)
+            r1 = _griddata_device(rho_, torch.atan2(y, x) * rho_, v, rhog, rhog * np.arctan2(gridy, gridx), method)
+            r2 = _griddata_device(rho_, torch.atan2(x, y) * rho_, v, rhog, rhog * np.arctan2(gridx, gridy), method)
+            n1, n2 = torch.isnan(r1), torch.isnan(r2)                 # np.nanmedian of two: their mean, or the one that is not NaN
+            res = torch.where(n1, r2, torch.where(n2, r1, (r1 + r2) / 2))
+        else:
+            res = _griddata_device(x, y, v, gridx, gridy, method)
+        return res, dx, dy
     from scipy.interpolate import griddata
     fused.flush()
     x = rays[1].detach().cpu().numpy()
@@ -345,7 +408,7 @@ def interpolateVec(rays, I, Nx, Ny, xr=None, yr=None, method='linear', polar=Fal
     return res, dx, dy
 
 
-def wavefront(rays, Nx, Ny, method='cubic', polar=False, maxiter=10000):
+def wavefront(rays, Nx, Ny, method='cubic', polar=False, maxiter=10000, on_device=False):
     """Interpolate the beam slopes onto an Nx x Ny grid and integrate the wavefront (Southwell SOR on the
     device, `native.reconstruct`); rays assumed in the xy plane (analyses.py:305-334).  Returns
     (phase, xslope, yslope) as NumPy arrays with NaN where there are no rays.
@@ -358,6 +421,21 @@ def wavefront(rays, Nx, Ny, method='cubic', polar=False, maxiter=10000):
     reference strips afterwards; `southwell.padArrays` does the same), criteria 1e-12, step dx, and
     `native.reconstruct`, which is bit-identical to the compiled reconstruct.f95."""
     from . import native
+    if on_device:
+        # the whole chain in HBM: device interpolation (method 'linear' / 'nearest'), the sentinel border and the NaN
+        # bookkeeping as tensor operations, the reconstructor as before; returns DEVICE tensors
+        ys, dx, dy = interpolateVec(rays, 5, Nx, Ny, method=method, polar=polar, on_device=True)
+        xs, dx, dy = interpolateVec(rays, 4, Nx, Ny, method=method, polar=polar, on_device=True)
+        pad = torch.nn.functional.pad
+        xs, ys = pad(xs, (1, 1, 1, 1), value=float("nan")), pad(ys, (1, 1, 1, 1), value=float("nan"))
+        bad = torch.isnan(xs) | torch.isnan(ys)
+        hundred = torch.full_like(xs, 100.)
+        gx, gy = native.fgrid(torch.where(bad, hundred, xs)), native.fgrid(torch.where(bad, hundred, ys))
+        gp = native.fgrid(torch.where(bad, hundred, torch.zeros_like(xs)))
+        out = native.reconstruct(gy, gx, 1e-12, float(dx), gp, int(maxiter))
+        nanv = torch.full_like(xs, float("nan"))
+        out = torch.where(out == 100, nanv, out)
+        return out[1:-1, 1:-1], torch.where(bad, nanv, xs)[1:-1, 1:-1], torch.where(bad, nanv, ys)[1:-1, 1:-1]
     ys, dx, dy = interpolateVec(rays, 5, Nx, Ny, method=method, polar=polar)
     xs, dx, dy = interpolateVec(rays, 4, Nx, Ny, method=method, polar=polar)
     xs = np.pad(np.asarray(xs, dtype=np.float64), 1, constant_values=np.nan)

@@ -223,3 +223,86 @@ def test_fused_focus_equals_the_five_separate_calls_bitwise(n, view):
                     assert np.array_equal(np.array(ca), np.array(cb))
                 for k, (u, v) in enumerate(zip(a, b)):
                     assert bits_equal(u.cpu().numpy(), v.cpu().numpy()).all(), (fname, wt, nr, k)
+
+
+def _cloud(rng, n, kind):
+    if kind == "blob":
+        x, y = rng.standard_normal(n) * 3., rng.standard_normal(n) * 2. + 1.
+    elif kind == "ring":                                   # an annulus: grid nodes in the hole are INSIDE the hull
+        r, t = np.sqrt(rng.uniform(40. ** 2, 50. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+        x, y = r * np.cos(t), r * np.sin(t)
+    else:                                                  # a thin tilted strip: skinny hull triangles
+        u, v = rng.uniform(-100, 100, n), rng.uniform(-1, 1, n)
+        x, y = u + .3 * v, .2 * u + v
+    return x, y
+
+
+@pytest.mark.parametrize("kind,n,grid", [("blob", 400, (9, 7)), ("blob", 20_000, (64, 48)), ("ring", 30_000, (57, 61)),
+                                         ("strip", 5_000, (40, 33)), ("blob", 300_000, (200, 150))])
+def test_interpolateVec_on_device_equals_scipy_griddata(kind, n, grid):
+    """interpolateVec(..., on_device=True) (pxf_griddata: per-node simplex walk to the Delaunay triangle, no host copy
+    of the rays) against the reference's own call, scipy.interpolate.griddata on the same points (analyses.py:227):
+    'linear' to 1e-12 (barycentric weights round differently), 'nearest' picks the same ray; NaN outside the convex hull
+    on the same nodes (a node within rounding of the hull's boundary may fall either way: at most a handful)."""
+    from scipy.interpolate import griddata
+    import pyxfocus_amd.analyses as anal
+    rng = np.random.default_rng(n + len(kind))
+    x, y = _cloud(rng, n, kind)
+    v = np.sin(.3 * x) * np.cos(.2 * y) + .01 * x * y
+    rays = [torch.from_numpy(c).cuda() for c in (np.zeros(n), x, y, np.zeros(n), v, -v, np.ones(n), x * 0, x * 0, x * 0 + 1)]
+    Nx, Ny = grid
+    gridx, gridy = np.meshgrid(np.linspace(x.min(), x.max(), Nx), np.linspace(y.min(), y.max(), Ny))
+    for meth in ("linear", "nearest"):
+        want = griddata((x, y), v, (gridx, gridy), method=meth)
+        got, dx, dy = anal.interpolateVec(rays, 4, Nx, Ny, method=meth, on_device=True)
+        assert isinstance(got, torch.Tensor) and got.is_cuda and tuple(got.shape) == (Ny, Nx)
+        got = got.cpu().numpy()
+        assert dx == np.diff(gridx)[0][0] and dy == np.diff(gridy.T)[0][0]
+        nan_w, nan_g = np.isnan(want), np.isnan(got)
+        assert (nan_w != nan_g).sum() <= 4 + (Nx + Ny) // 8, (kind, meth, (nan_w != nan_g).sum())
+        both = ~nan_w & ~nan_g
+        assert both.sum() > (30 if kind == "strip" else .3 * Nx * Ny)
+        if meth == "nearest":
+            assert (got[both] != want[both]).mean() < 1e-3          # (equidistant ties may be broken differently)
+        else:
+            err = np.abs(got[both] - want[both])
+            assert err.max() <= 1e-12 * (1. + np.abs(v).max()), (kind, n, err.max())
+    # explicit range reaching beyond the cloud, another column, polar coordinates
+    got = anal.interpolateVec(rays, 0, 21, 17, xr=[x.min() - 1., x.max() + 2.], yr=[y.min() - .5, y.max() + .5],
+                              interpVec=rays[5], on_device=True)[0].cpu().numpy()
+    gx2, gy2 = np.meshgrid(np.linspace(x.min() - 1., x.max() + 2., 21), np.linspace(y.min() - .5, y.max() + .5, 17))
+    want = griddata((x, y), -v, (gx2, gy2), method="linear")
+    assert (np.isnan(want) != np.isnan(got)).sum() <= 6
+    ok = ~np.isnan(want) & ~np.isnan(got)
+    assert np.abs(got[ok] - want[ok]).max() <= 1e-12 * (1. + np.abs(v).max())
+    if kind == "blob" and n <= 20_000:
+        want = anal.interpolateVec(rays, 4, 12, 11, polar=True)[0]
+        got = anal.interpolateVec(rays, 4, 12, 11, polar=True, on_device=True)[0].cpu().numpy()
+        ok = ~np.isnan(want) & ~np.isnan(got)
+        assert (np.isnan(want) != np.isnan(got)).sum() <= 6 and ok.sum() > 20
+        assert np.abs(got[ok] - want[ok]).max() <= 1e-9 * (1. + np.abs(v).max())      # (theta * rho: atan2 differs by ulps)
+
+
+def test_wavefront_on_device_equals_host_pipeline():
+    """analyses.wavefront(method='linear', on_device=True): interpolation, sentinel border and reconstruction without a
+    host copy -- against the host pipeline (scipy griddata + the same device reconstructor)."""
+    import pyxfocus_amd.analyses as anal
+    rng = np.random.default_rng(3)
+    n = 40_000
+    x, y = rng.uniform(-10, 10, n), rng.uniform(-8, 8, n)
+    keep = x ** 2 / 100. + y ** 2 / 64. < 1.
+    x, y = x[keep], y[keep]
+    n = len(x)
+    l, m = -x / 500., -y / 500.                                    # a beam converging to z = 500
+    rays = [torch.from_numpy(c).cuda() for c in (np.zeros(n), x, y, np.zeros(n), l, m, -np.sqrt(1 - l * l - m * m),
+                                                  x * 0, x * 0, x * 0 + 1)]
+    ph_h, xs_h, ys_h = anal.wavefront(rays, 31, 27, method="linear")
+    ph_d, xs_d, ys_d = anal.wavefront(rays, 31, 27, method="linear", on_device=True)
+    assert ph_d.is_cuda
+    for a, b in ((ph_h, ph_d), (xs_h, xs_d), (ys_h, ys_d)):
+        b = b.cpu().numpy()
+        assert (np.isnan(a) != np.isnan(b)).sum() <= 6
+        ok = ~np.isnan(a) & ~np.isnan(b)
+        assert ok.sum() > 400
+    ok = ~np.isnan(xs_h) & ~np.isnan(xs_d.cpu().numpy())
+    assert np.abs(xs_d.cpu().numpy()[ok] - xs_h[ok]).max() < 1e-13
