@@ -56,16 +56,6 @@ int blocks_per_cu_cap()
     return bpc;
 }
 
-bool xcd_remap_enabled()
-{
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("PXF_XCD_REMAP");
-        on = e ? (atoi(e) != 0) : 0;  // measured on MI355X: the XCD-contiguous mapping LOSES 4 %
-    }
-    return on != 0;
-}
-
 bool use_nt(int64_t num)
 {
     static int64_t min_rays = -1;

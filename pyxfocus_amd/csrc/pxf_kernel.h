@@ -121,21 +121,12 @@ struct Ray {
 //   static constexpr unsigned RD, WR;            column bitmasks
 //   template<int V> __device__ void apply(Ray (&r)[V], const bool (&sel)[V], unsigned (&wm)[V]) const;
 // `sel[v]` says whether ray v takes part (mask / tail), `wm[v]` receives the columns to store.
-// Workgroup -> tile mapping.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share
-// one), so the identity mapping makes every XCD touch every 8th 4-KiB tile of every column, i.e.
-// every page of the bundle.  With xcd_chunk > 0 the grid is re-indexed so that each XCD streams
-// one CONTIGUOUS eighth of each column: an XCD's translation caches then only ever see 1/8 of the
-// pages.  (Speed only; any placement gives the same result.)  MEASURED (tools/ab_env.sh
-// PXF_XCD_REMAP 0 1): the contiguous mapping is 4 % SLOWER on every kernel of the chain -- the
-// in-order sweep of all 8 XCDs over neighbouring DRAM pages matters more than translation reach --
-// so the identity mapping is the default and the remap stays only as an opt-in experiment.
-__device__ __forceinline__ int64_t tile_of_block(int64_t b, int64_t nblocks, int64_t xcd_chunk)
-{
-    if (xcd_chunk <= 0) return b;
-    const int64_t t = (b & 7) * xcd_chunk + (b >> 3);
-    return t;  // may be >= nblocks for the ragged tail: the caller's bound check drops it
-}
-
+// One workgroup per 256 ray-vectors, NO grid-stride loop.  Round 1 measured the uncapped grid 6 % ahead of "8 workgroups
+// per CU + grid-stride" for the streaming kernels, and an XCD-contiguous tile mapping 4 % behind the identity one
+// (profiles/r01_ab_grid_nt_variants.txt; both knobs are gone since round 3).  Round 3 found what the loop cost the
+// compute-bound kernels: every wave-uniform quantity of the Op is loop-invariant, is hoisted in front of the loop and,
+// for want of SGPRs, spilled to VGPR lanes (the W-S and Legendre-Legendre kernels carried 50-100 v_writelane /
+// v_readlane each; without the loop: none).
 // An Op may ask for a minimum occupancy (waves per SIMD) with `static constexpr int MIN_WAVES`: the
 // second __launch_bounds__ argument caps its VGPR budget accordingly (512 / MIN_WAVES per lane).
 // The default is 2, never 1: a 512-register budget lets the compiler park VGPRs in AGPRs, and its reload path for
@@ -153,11 +144,11 @@ struct min_waves<T, decltype((void)T::MIN_WAVES)> {
 
 template <class Op, int V, bool MASKED, bool NT>
 __global__ __launch_bounds__(kBlock, min_waves<Op>::value) void ray_kernel(Cols c, int64_t first, int64_t nvec,
-                                                     const uint8_t *__restrict__ mask, Op op, int64_t xcd_chunk)
+                                                     const uint8_t *__restrict__ mask, Op op)
 {
     op.prologue();  // block-wide setup (LDS staging); no-op for most Ops
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t v = tile_of_block(blockIdx.x, gridDim.x, xcd_chunk) * kBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v < nvec) {
         Ray r[V];
         bool sel[V];
         unsigned wm[V];
@@ -234,19 +225,8 @@ inline int grid_for(int64_t nvec)
     return (int)(want < cap ? want : cap);
 }
 
-bool xcd_remap_enabled();  // env PXF_XCD_REMAP=1 (default off: measured slower)
-
-// Uncapped grid rounded up to a multiple of 8 workgroups, plus the per-XCD chunk length for
-// tile_of_block (0 = identity mapping: capped grids, tiny launches, or remap disabled).
-inline int grid_xcd(int64_t nvec, int64_t &chunk)
-{
-    const int g = grid_for(nvec);
-    const int64_t want = (nvec + kBlock - 1) / kBlock;
-    chunk = 0;
-    if (!xcd_remap_enabled() || g != want || want < 64) return g;
-    chunk = (want + 7) / 8;
-    return (int)(chunk * 8);
-}
+// one workgroup per kBlock vectors, never capped: for the kernels that have no grid-stride loop
+inline unsigned grid_exact(int64_t nvec) { return (unsigned)((nvec + kBlock - 1) / kBlock); }
 
 inline int grid_capped(int64_t nvec)  // reductions: one partial row per workgroup, bounded workspace
 {
@@ -272,12 +252,7 @@ int launch_rays(const Cols &c, int64_t num, const uint8_t *mask, pxf_stream_t st
     const bool nt = use_nt(num);
     int64_t nvec2 = 0;
 #define PXF_LAUNCH(V, M, T, FIRST, NVEC)                                                         \
-    do {                                                                                         \
-        int64_t chunk_ = 0;                                                                      \
-        const int g_ = grid_xcd(NVEC, chunk_);                                                   \
-        hipLaunchKernelGGL((ray_kernel<Op, V, M, T>), dim3(g_), dim3(kBlock), 0, s, c, FIRST, NVEC, mask, \
-                           op, chunk_);                                                          \
-    } while (0)
+    hipLaunchKernelGGL((ray_kernel<Op, V, M, T>), dim3(grid_exact(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, mask, op)
 #define PXF_LAUNCH_V(V, FIRST, NVEC)                 \
     do {                                             \
         if (mask) {                                  \

@@ -22,8 +22,8 @@ namespace pxf {
 template <int V, bool NT, bool ANYMASK, bool HOT = false>
 __global__ __launch_bounds__(kBlock, 2) void program_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // no grid-stride loop (pxf_kernel.h: ray_kernel)
+    if (v < nvec) {
         const int64_t vv = first + v;
         Ray r[V];
 #pragma unroll
@@ -183,8 +183,7 @@ struct Chain {
     template <int V, bool NT>
     static void launch(hipStream_t s, const Cols &c, int64_t first, int64_t nvec, const Program &pg)
     {
-        hipLaunchKernelGGL((program_chain_kernel<V, NT, CODES...>), dim3((unsigned)((nvec + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, c, first, nvec, pg);
+        hipLaunchKernelGGL((program_chain_kernel<V, NT, CODES...>), dim3(grid_exact(nvec)), dim3(kBlock), 0, s, c, first, nvec, pg);
     }
 };
 // BASELINE config 2: transform, wolterprimary, reflect, woltersecondary, reflect, flat
@@ -582,9 +581,9 @@ int pxf_program_run(const pxf_op_t *ops, int32_t nops, double *const *cols, int6
 #define PXF_PLAUNCH(V, T, A, FIRST, NVEC)                                                                             \
     do {                                                                                                              \
         if (hot && !(A))                                                                                              \
-            hipLaunchKernelGGL((program_kernel<V, T, false, true>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg); \
+            hipLaunchKernelGGL((program_kernel<V, T, false, true>), dim3(grid_exact(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg); \
         else                                                                                                          \
-            hipLaunchKernelGGL((program_kernel<V, T, A>), dim3(grid_for(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg);  \
+            hipLaunchKernelGGL((program_kernel<V, T, A>), dim3(grid_exact(NVEC)), dim3(kBlock), 0, s, c, FIRST, NVEC, pg);  \
     } while (0)
 #define PXF_PLAUNCH_V(V, FIRST, NVEC)                      \
     do {                                                   \

@@ -362,8 +362,8 @@ static bool fast_supported(const Program &pg)
 template <int V, bool NT, int... CODES>
 __global__ __launch_bounds__(kBlock, 2) void program_fast_kernel(Cols c, int64_t first, int64_t nvec, Program pg)
 {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // no grid-stride loop (pxf_kernel.h: ray_kernel)
+    if (v < nvec) {
         const int64_t vv = first + v;
         Ray r[V];
 #pragma unroll
@@ -495,12 +495,12 @@ int pxf_program_run_fast(const pxf_op_t *ops, int32_t nops, double *const *cols,
 #define PXF_FAST_LAUNCH(...)                                                                                              \
     do {                                                                                                                  \
         if (nvec2 > 0) {                                                                                                  \
-            if (nt) hipLaunchKernelGGL((program_fast_kernel<2, true __VA_ARGS__>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg); \
-            else hipLaunchKernelGGL((program_fast_kernel<2, false __VA_ARGS__>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);  \
+            if (nt) hipLaunchKernelGGL((program_fast_kernel<2, true __VA_ARGS__>), dim3(grid_exact(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg); \
+            else hipLaunchKernelGGL((program_fast_kernel<2, false __VA_ARGS__>), dim3(grid_exact(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pg);  \
         }                                                                                                                 \
         if (rest > 0) {                                                                                                   \
-            if (nt) hipLaunchKernelGGL((program_fast_kernel<1, true __VA_ARGS__>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pg); \
-            else hipLaunchKernelGGL((program_fast_kernel<1, false __VA_ARGS__>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pg);  \
+            if (nt) hipLaunchKernelGGL((program_fast_kernel<1, true __VA_ARGS__>), dim3(grid_exact(rest)), dim3(kBlock), 0, s, c, done, rest, pg); \
+            else hipLaunchKernelGGL((program_fast_kernel<1, false __VA_ARGS__>), dim3(grid_exact(rest)), dim3(kBlock), 0, s, c, done, rest, pg);  \
         }                                                                                                                 \
     } while (0)
 #define PXF_C2 PXF_OP_TRANSFORM, PXF_OP_WOLTERPRIMARY, PXF_OP_REFLECT, PXF_OP_WOLTERSECONDARY, PXF_OP_REFLECT, PXF_OP_FLAT

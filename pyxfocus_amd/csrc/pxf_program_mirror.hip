@@ -127,8 +127,8 @@ template <int KT1, bool NT>
 __global__ __launch_bounds__(kBlock, 2) void program_mirror_kernel(Cols c, int64_t nvec, ProgramM pg, MirrorPool pool)
 {
     constexpr int V = 1;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t vv = (int64_t)blockIdx.x * kBlock + threadIdx.x; vv < nvec; vv += stride) {
+    const int64_t vv = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // no grid-stride loop (pxf_kernel.h: ray_kernel)
+    if (vv < nvec) {
         Ray r[V];
 #pragma unroll
         for (int col = 0; col < 10; col++) {
@@ -155,7 +155,7 @@ template <int KT1>
 static int launch_mirror_kt(const ProgramM &pm, const MirrorPool &pool, const Cols &c, int64_t num, pxf_stream_t stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for(num)), block(kBlock);
+    const dim3 grid(grid_exact(num)), block(kBlock);
     if (use_nt(num)) hipLaunchKernelGGL((program_mirror_kernel<KT1, true>), grid, block, 0, s, c, num, pm, pool);
     else hipLaunchKernelGGL((program_mirror_kernel<KT1, false>), grid, block, 0, s, c, num, pm, pool);
     hipError_t e = hipGetLastError();

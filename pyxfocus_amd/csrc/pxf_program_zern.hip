@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kBlock, PXF_ZPROG_WAVES) void program_zern_kernel(C
                                                                                       ProgramZ pg, ZernOp<NMAX, false> zop, int iz)
 {
     zop.prologue();  // Zernike table -> LDS (contains the barrier: before any thread may exit)
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;   // no grid-stride loop (pxf_kernel.h: ray_kernel)
+    if (v < nvec) {
         const int64_t vv = first + v;
         Ray r[V];
 #pragma unroll
@@ -131,14 +131,14 @@ static int launch_zern_nmax(const ProgramZ &pz, int iz, const ZernTab &tab, cons
     const bool nt = use_nt(num);
     const int64_t nvec2 = aligned ? num / 2 : 0;
     if (nvec2 > 0) {
-        if (nt) hipLaunchKernelGGL((program_zern_kernel<NMAX, 2, true>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pz, zop, iz);
-        else hipLaunchKernelGGL((program_zern_kernel<NMAX, 2, false>), dim3(grid_for(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pz, zop, iz);
+        if (nt) hipLaunchKernelGGL((program_zern_kernel<NMAX, 2, true>), dim3(grid_exact(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pz, zop, iz);
+        else hipLaunchKernelGGL((program_zern_kernel<NMAX, 2, false>), dim3(grid_exact(nvec2)), dim3(kBlock), 0, s, c, (int64_t)0, nvec2, pz, zop, iz);
     }
     const int64_t done = nvec2 * 2;
     if (done < num) {
         const int64_t rest = num - done;
-        if (nt) hipLaunchKernelGGL((program_zern_kernel<NMAX, 1, true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pz, zop, iz);
-        else hipLaunchKernelGGL((program_zern_kernel<NMAX, 1, false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, c, done, rest, pz, zop, iz);
+        if (nt) hipLaunchKernelGGL((program_zern_kernel<NMAX, 1, true>), dim3(grid_exact(rest)), dim3(kBlock), 0, s, c, done, rest, pz, zop, iz);
+        else hipLaunchKernelGGL((program_zern_kernel<NMAX, 1, false>), dim3(grid_exact(rest)), dim3(kBlock), 0, s, c, done, rest, pz, zop, iz);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PXF_OK : hip_fail(e);
