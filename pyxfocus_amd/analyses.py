@@ -419,7 +419,13 @@ def wavefront(rays, Nx, Ny, method='cubic', polar=False, maxiter=10000, on_devic
     is not vendored.  What it evidently intends is built from pinned pieces: `interpolateVec` (the reference's
     own griddata call), a one-cell border of the reconstructor's NaN sentinel (the `[1:-1, 1:-1]` the
     reference strips afterwards; `southwell.padArrays` does the same), criteria 1e-12, step dx, and
-    `native.reconstruct`, which is bit-identical to the compiled reconstruct.f95."""
+    `native.reconstruct`, which is bit-identical to the compiled reconstruct.f95.  One deliberate difference from
+    the reference text: a cell counts as empty when EITHER slope is NaN (the reference marks `phase` where the x slope
+    is NaN only, analyses.py:318-320); both slope maps come from the same griddata triangulation, so the two masks
+    coincide whenever the inputs are finite.
+
+    ``on_device=True`` (an addition; method 'linear' or 'nearest'): interpolation (pxf_griddata), border, masks and
+    reconstruction all stay in HBM and the three results are device tensors."""
     from . import native
     if on_device:
         # the whole chain in HBM: device interpolation (method 'linear' / 'nearest'), the sentinel border and the NaN
