@@ -610,12 +610,15 @@ int pxf_fan_finish(double *const *cols, int64_t num, double ang, double dpermm, 
  * scipy's griddata returns, to the rounding of the barycentric weights, for points in general position.
  * The caller supplies the points SORTED BY CELL of a uniform gx x gy grid over their bounding box -- cell (i, j) =
  * [x0 + i / inv_cell_x, ...) x [y0 + j / inv_cell_y, ...), id j * gx + i -- and cell_start[gx * gy + 1] (device int32,
- * offsets of each cell's points); about two points per cell is a good density.  support16 (HOST, may be NULL):
- * max_i (x_i cos a_k + y_i sin a_k), a_k = 2 pi k / 16 -- a cheap "outside the hull" test for queries beyond the cloud.
- * All other pointers are device pointers; out[m]. */
+ * offsets of each cell's points); about two points per cell is a good density.  support (HOST double[64], may be NULL):
+ * max_i (x_i cos a_k + y_i sin a_k), a_k = 2 pi k / 64 -- a cheap "outside the hull" test for queries beyond the cloud.
+ * All other pointers are device pointers; out[m]; workspace: pxf_griddata_workspace_bytes(m) bytes (the queue of the
+ * nodes at the rim of the cloud, which a second kernel settles with one workgroup each). */
+size_t pxf_griddata_workspace_bytes(int64_t m);
 int pxf_griddata(const double *xs, const double *ys, const double *vs, int64_t n, const int32_t *cell_start, int32_t gx,
-                 int32_t gy, double x0, double y0, double inv_cell_x, double inv_cell_y, const double *support16,
-                 const double *qx, const double *qy, int64_t m, int32_t method, double *out, pxf_stream_t stream);
+                 int32_t gy, double x0, double y0, double inv_cell_x, double inv_cell_y, const double *support,
+                 const double *qx, const double *qy, int64_t m, int32_t method, double *out, void *workspace,
+                 pxf_stream_t stream);
 
 /* ---- OPT-IN tolerance mode of the fused program ------------------------------------------------------
  * pxf_program_run / pxf_program_run_segments are bit-identical to the reference's loops

@@ -105,7 +105,8 @@ _SIGS = {
     "pxf_wselect_pick": [_i32, _P, _i32, _P],
     "pxf_wselect_neighbors": [_P, _i64, _i32, _P, _P],
     "pxf_wselect_finish": [_i32, _P, _P, _P],
-    "pxf_griddata": [_P, _P, _P, _i64, _P, _i32, _i32, _d, _d, _d, _d, _DP, _P, _P, _i64, _i32, _P, _P],
+    "pxf_griddata_workspace_bytes": [_i64],
+    "pxf_griddata": [_P, _P, _P, _i64, _P, _i32, _i32, _d, _d, _d, _d, _DP, _P, _P, _i64, _i32, _P, _P, _P],
     "pxf_southwellbin_workspace_bytes": [_i32, _i32],
     "pxf_southwellbin": [_P, _P, _P, _P, _i64, _d, _P, _P, _P, _i32, _i32, _P, _P],
     "pxf_reconstruct": [_P, _P, _i32, _i32, _d, _d, _P, _P, _i32, _P, _P],
@@ -126,7 +127,8 @@ _RESTYPE = {"pxf_strerror": C.c_char_p, "pxf_wolter_params": None,
             "pxf_compact_workspace_bytes": C.c_size_t, "pxf_reduce_workspace_bytes": C.c_size_t,
             "pxf_select_workspace_bytes": C.c_size_t, "pxf_southwellbin_workspace_bytes": C.c_size_t,
             "pxf_select_passes": C.c_int32, "pxf_select_state_layout": None,
-            "pxf_wselect_workspace_bytes": C.c_size_t, "pxf_radial_kth_workspace_bytes": C.c_size_t, "pxf_wselect_state_layout": None}
+            "pxf_wselect_workspace_bytes": C.c_size_t, "pxf_radial_kth_workspace_bytes": C.c_size_t, "pxf_wselect_state_layout": None,
+            "pxf_griddata_workspace_bytes": C.c_size_t}
 
 EXPORTS = tuple(_SIGS)
 _lib = None

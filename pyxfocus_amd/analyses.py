@@ -337,13 +337,18 @@ def _griddata_device(px, py, pv, qx, qy, method):
     cid, order = torch.sort(cj * g + ci, stable=True)
     xs, ys, vs = px[order].contiguous(), py[order].contiguous(), pv.to(torch.float64)[order].contiguous()
     start = torch.searchsorted(cid, torch.arange(g * g + 1, device=dev, dtype=torch.int64)).to(torch.int32)
-    sup = (C.c_double * 16)(*[float((px * math.cos(2 * math.pi * k / 16) + py * math.sin(2 * math.pi * k / 16)).max())
-                              for k in range(16)])
+    ang = torch.arange(64, dtype=torch.float64, device=dev) * (2 * math.pi / 64)
+    supt = torch.full((64,), -float("inf"), dtype=torch.float64, device=dev)
+    for lo in range(0, n, 1 << 22):                       # 64 directional maxima in slabs of 4M rays (bounded temporaries)
+        sl = slice(lo, lo + (1 << 22))
+        supt = torch.maximum(supt, (torch.cos(ang)[:, None] * px[sl][None, :] + torch.sin(ang)[:, None] * py[sl][None, :]).max(dim=1).values)
+    sup = (C.c_double * 64)(*supt.tolist())
     qd = torch.from_numpy(q).to(dev)
+    ws = torch.empty(_lib.lib().pxf_griddata_workspace_bytes(m), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().pxf_griddata(xs.data_ptr(), ys.data_ptr(), vs.data_ptr(), n, start.data_ptr(), g, g, x0, y0, icx, icy,
                                      sup, qd[0].data_ptr(), qd[1].data_ptr(), m, 1 if method == "linear" else 0,
-                                     out.data_ptr(), native._stream(dev))
+                                     out.data_ptr(), ws.data_ptr(), native._stream(dev))
     _lib.check(rc, "pxf_griddata")
     return out.reshape(np.shape(qx))
 

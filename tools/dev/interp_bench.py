@@ -28,7 +28,9 @@ def main():
         res = anal.interpolateVec(rays, 4, g, g, method=meth, on_device=True)[0]
         torch.cuda.synchronize()
         out["device_%s_ms" % meth] = (time.perf_counter() - t0) * 1e3
-        out["inside_fraction"] = float((~torch.isnan(res)).double().mean())
+        if meth == "linear":
+            out["inside_fraction"] = float((~torch.isnan(res)).double().mean())
+        sys.stderr.write("%s done\n" % meth)
     if n <= 2_000_000:
         t0 = time.perf_counter()
         want = anal.interpolateVec(rays, 4, g, g, method="linear")[0]
