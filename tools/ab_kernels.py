@@ -32,7 +32,10 @@ def load(path, bpc, tmp, name):
     os.environ["PXF_BPC"] = str(bpc)
     h = C.CDLL(dst)
     for fn, argtypes in _lib._SIGS.items():
-        f = getattr(h, fn)
+        try:
+            f = getattr(h, fn)
+        except AttributeError:          # an older build variant without a newer entry point
+            continue
         f.argtypes = argtypes
         f.restype = _lib._RESTYPE.get(fn, C.c_int)
     return h
