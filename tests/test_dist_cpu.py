@@ -111,6 +111,8 @@ def _gather_worker(rank, world, port, counts, scratch, q):
     ((0, 513), 24 * 100),            # an empty shard
     ((0, 0), None),                  # nothing survived anywhere
     ((5, 7, 6), 32 * 2),             # three ranks, 2-element chunks
+    ((40, 0, 7, 33, 33, 1, 90, 12), 72 * 5),   # the driver's world size: eight ranks, uneven, one empty, 5-element chunks
+    ((64,) * 8, None),               # eight ranks, equal shards (config 5 when every ray survives)
 ])
 def test_all_gather_focal_bounded_memory_paths(counts, scratch):
     world = len(counts)
