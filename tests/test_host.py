@@ -419,3 +419,24 @@ def test_ws_back_sincos_atan2_matches_libm_bitwise():
     assert _lib.lib().pxf_host_sincos_atan2(yy.ctypes.data_as(dp), xx.ctypes.data_as(dp), t.ctypes.data_as(dp),
                                             s_.ctypes.data_as(dp), c_.ctypes.data_as(dp), 4) == 0
     assert np.isnan(t).all()
+
+
+def test_no_usable_device_is_reported_as_enodev():
+    """include/pxf.h: PXF_ENODEV.  Without a gfx950 device (this CPU container) `pxf_device_check` says so, and a launch
+    entry returns PXF_ENODEV before it looks at a pointer -- it used to be declared but never returned.
+    On a GPU box the same calls are fine: the check returns PXF_OK."""
+    import ctypes as C
+    import torch
+    from pyxfocus_amd import _lib
+    h = _lib.lib()
+    rc = h.pxf_device_check()
+    if torch.cuda.is_available():
+        assert rc == 0
+        return
+    assert rc == -3 and b"gfx950" in h.pxf_strerror(rc)
+    buf = (C.c_double * 8)()
+    p = C.addressof(buf)                       # host memory: never dereferenced, the entry returns first
+    assert h.pxf_flat(*[p] * 9, 4, None, None) == -3
+    assert h.pxf_flat(*[p] * 9, 0, None, None) == 0          # an empty bundle stays a no-op
+    out = (C.c_uint64 * 1)()
+    assert h.pxf_selftest_exact_division(16, 1, C.addressof(out), None) == -3
