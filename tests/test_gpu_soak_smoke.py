@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     ("grating_soak.py", ["6", "103"], "grating soak: 0 mismatches"),
     ("source_soak.py", ["6", "104"], "source soak: 0 mismatches"),
     ("fast_soak.py", ["6", "105"], "tolerance-mode soak: worst RMS"),
+    ("fan_soak.py", ["4", "106"], "fan soak: 4 iterations, 0 mismatches"),
 ])
 def test_soak_scripts_run_clean(script, args, ok):
     r = subprocess.run([sys.executable, os.path.join(HERE, "soak", script)] + args, capture_output=True, text=True, timeout=600)
