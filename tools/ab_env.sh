@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B an environment knob on the real bench, alternating runs on the same box.
+# A/B an environment knob on the real bench, alternating runs on the same box (e.g. PXF_NT_MIN_RAYS,
+# PXF_PROGRAM_NO_CHAIN; the round-1 grid knobs PXF_BPC / PXF_XCD_REMAP no longer reach the ray kernels, which have
+# no grid-stride loop since round 3).
 # usage: tools/ab_env.sh VAR val1 val2 [rounds]
 VAR=$1; A=$2; B=$3; R=${4:-2}
 for r in $(seq 1 $R); do

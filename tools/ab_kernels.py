@@ -3,7 +3,7 @@
 
 usage: ab_kernels.py name=path[:BPC] ...     e.g.  base=pyxfocus_amd/csrc/libpxf_hip.so:0 nt=build/libpxf_hip_nt.so:0
 Each variant is a copy of a libpxf_hip build loaded under its own name (own statics), with its own
-PXF_BPC.  Per round every variant traces a fresh config-2 bundle; each launch is bracketed by HIP
+PXF_BPC (a grid cap: honoured by builds up to round 2 only -- the ray kernels have had no grid-stride loop since).  Per round every variant traces a fresh config-2 bundle; each launch is bracketed by HIP
 events.  Prints median/min ms and GB/s per kernel per variant.
 """
 import ctypes as C
